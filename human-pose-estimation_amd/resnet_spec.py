@@ -1,0 +1,55 @@
+"""ResNet-50 v1 conv-layer table for the encoder the reference instantiates with
+``tensorflow.keras.applications.ResNet50(include_top=False, pooling='avg')``
+(reference: src/models.py:35-41; topology per SURVEY.md §8(a) row 1).
+
+This is the canonical layer ORDER of the C-ABI (``include/hpe.h``: ``hpe_load_conv`` takes the index
+into this table).  Layer names are the Keras ones (``conv1``, ``res2a_branch2a`` … with the matching
+``bn*`` BatchNorm), so a Keras-layout weight dict keyed by layer name maps 1:1.
+
+Each entry: (name, bn_name, KH, KW, Cin, Cout, stride, Hin, Hout).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+ConvSpec = namedtuple("ConvSpec", "name bn_name kh kw cin cout stride hin hout")
+
+STAGE_BLOCKS = {2: 3, 3: 4, 4: 6, 5: 3}
+STAGE_FILTERS = {2: (64, 64, 256), 3: (128, 128, 512), 4: (256, 256, 1024), 5: (512, 512, 2048)}
+
+
+def resnet50_conv_specs():
+    specs = [ConvSpec("conv1", "bn_conv1", 7, 7, 3, 64, 2, 224, 112)]
+    cin, h = 64, 56  # after 3x3/2 max-pool
+    for stage in (2, 3, 4, 5):
+        f1, f2, f3 = STAGE_FILTERS[stage]
+        for b in range(STAGE_BLOCKS[stage]):
+            blk = "abcdef"[b]
+            first = b == 0
+            s = 2 if (first and stage > 2) else 1
+            hout = h // s
+            base = "res%d%s_branch" % (stage, blk)
+            bn = "bn%d%s_branch" % (stage, blk)
+            specs.append(ConvSpec(base + "2a", bn + "2a", 1, 1, cin, f1, s, h, hout))
+            specs.append(ConvSpec(base + "2b", bn + "2b", 3, 3, f1, f2, 1, hout, hout))
+            specs.append(ConvSpec(base + "2c", bn + "2c", 1, 1, f2, f3, 1, hout, hout))
+            if first:
+                specs.append(ConvSpec(base + "1", bn + "1", 1, 1, cin, f3, s, h, hout))
+            cin, h = f3, hout
+    return specs
+
+
+CONV_SPECS = resnet50_conv_specs()
+CONV_INDEX = {s.name: i for i, s in enumerate(CONV_SPECS)}
+
+
+def encoder_param_count():
+    n = 0
+    for s in CONV_SPECS:
+        n += s.kh * s.kw * s.cin * s.cout + s.cout  # kernel + bias
+        n += 4 * s.cout  # BN gamma, beta, moving_mean, moving_variance
+    return n
+
+
+def encoder_macs_per_image():
+    return sum(s.kh * s.kw * s.cin * s.cout * s.hout * s.hout for s in CONV_SPECS)

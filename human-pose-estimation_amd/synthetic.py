@@ -1,0 +1,223 @@
+"""Seeded synthetic assets with the exact shapes/layouts of the licensed or remote files the reference
+loads but does not ship:
+
+* an SMPL-shaped body model   -- stands in for ``models/model.pkl`` (reference: src/tf_smpl/batch_smpl.py:31-81)
+* mean theta                  -- stands in for ``neutral_smpl_mean_params.h5`` (reference: src/predictor.py:88-110)
+* ResNet-50 v1 encoder params -- Keras layouts (conv HWIO + bias, BN gamma/beta/moving_mean/moving_variance)
+* regressor params            -- Keras Dense layouts ([in, out] kernel + bias) (reference: src/models.py:60-74)
+* 224x224x3 images in [-1, 1) -- reference input contract (src/util/data_utils.py:72-80)
+
+Everything is generated from counter-based Philox streams, so the build container and the GPU box
+regenerate bit-identical arrays from the seeds (94 MB of weights is not a fixture to ship).
+
+This module is product-side plumbing for benchmarks/tests; it contains no forward math.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .resnet_spec import CONV_SPECS
+
+NUM_VERTS = 6890
+NUM_JOINTS = 24
+NUM_KP = 19
+NUM_BETAS = 10
+NUM_POSE_BASIS = 207
+TOTAL_PARAMS = 85
+
+# kintree_table[0] of the SMPL model (root's parent is uint32(-1) -> int32 -1; batch_smpl.py:65)
+SMPL_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], dtype=np.int32
+)
+
+# rough rest-pose joint centres (metres), SMPL joint order
+_REST_JOINTS = np.array(
+    [
+        [0.00, -0.24, 0.03],  # 0 pelvis
+        [0.07, -0.33, 0.02],  # 1 l hip
+        [-0.07, -0.33, 0.02],  # 2 r hip
+        [0.00, -0.12, 0.00],  # 3 spine1
+        [0.10, -0.71, 0.02],  # 4 l knee
+        [-0.10, -0.71, 0.02],  # 5 r knee
+        [0.00, 0.02, 0.02],  # 6 spine2
+        [0.09, -1.11, -0.02],  # 7 l ankle
+        [-0.09, -1.11, -0.02],  # 8 r ankle
+        [0.00, 0.07, 0.04],  # 9 spine3
+        [0.12, -1.17, 0.10],  # 10 l foot
+        [-0.12, -1.17, 0.10],  # 11 r foot
+        [0.00, 0.28, 0.00],  # 12 neck
+        [0.08, 0.19, 0.01],  # 13 l collar
+        [-0.08, 0.19, 0.01],  # 14 r collar
+        [0.00, 0.36, 0.04],  # 15 head
+        [0.17, 0.22, 0.00],  # 16 l shoulder
+        [-0.17, 0.22, 0.00],  # 17 r shoulder
+        [0.43, 0.21, -0.02],  # 18 l elbow
+        [-0.43, 0.21, -0.02],  # 19 r elbow
+        [0.68, 0.22, -0.02],  # 20 l wrist
+        [-0.68, 0.22, -0.02],  # 21 r wrist
+        [0.77, 0.21, -0.03],  # 22 l hand
+        [-0.77, 0.21, -0.03],  # 23 r hand
+    ],
+    dtype=np.float64,
+)
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.Philox(int(seed)))
+
+
+def make_smpl_model(seed=3):
+    """SMPL-shaped model dict with the keys/shapes of the reference's ``model.pkl`` after the
+    chumpy/scipy-sparse conversions of batch_smpl.py:31-81 (all dense numpy):
+
+      v_template [6890,3], shapedirs [6890,3,10], posedirs [6890,3,207], J_regressor [24,6890],
+      weights [6890,24], cocoplus_regressor [19,6890], kintree_table [2,24].
+    """
+    g = _rng(seed)
+    V, J = NUM_VERTS, NUM_JOINTS
+    # vertices scattered around the bones of the rest skeleton
+    bone = g.integers(1, J, size=V)
+    par = SMPL_PARENTS[bone]
+    tpos = g.random(V)[:, None]
+    centre = _REST_JOINTS[par] * (1 - tpos) + _REST_JOINTS[bone] * tpos
+    v_template = centre + g.normal(0.0, 0.045, size=(V, 3))
+    # head blob so that face keypoints have something to sit on
+    head = g.random(V) < 0.08
+    v_template[head] = _REST_JOINTS[15] + np.array([0, 0.09, 0.02]) + g.normal(0, 0.06, size=(int(head.sum()), 3))
+
+    shapedirs = g.normal(0.0, 0.004, size=(V, 3, NUM_BETAS))
+    for k in range(NUM_BETAS):
+        axis = k % 3
+        shapedirs[:, axis, k] += (0.03 / (1 + k // 3)) * v_template[:, axis]
+    posedirs = g.normal(0.0, 0.004, size=(V, 3, NUM_POSE_BASIS))
+
+    d2 = ((v_template[:, None, :] - _REST_JOINTS[None, :, :]) ** 2).sum(-1)  # [V, 24]
+    # LBS weights: 4 nearest joints, soft falloff, rows sum to 1 (dense storage like the reference)
+    nearest = np.argsort(d2, axis=1)[:, :4]
+    wsel = np.exp(-np.take_along_axis(d2, nearest, 1) / (2 * 0.08**2)) + 1e-6
+    wsel /= wsel.sum(1, keepdims=True)
+    weights = np.zeros((V, J))
+    np.put_along_axis(weights, nearest, wsel, 1)
+
+    # joint regressor: each joint = convex combination of its 32 nearest vertices
+    J_regressor = np.zeros((J, V))
+    for j in range(J):
+        idx = np.argsort(d2[:, j])[:32]
+        w = g.random(32) + 0.1
+        J_regressor[j, idx] = w / w.sum()
+
+    # 19 cocoplus keypoints: convex combinations of local vertex patches
+    cocoplus = np.zeros((NUM_KP, V))
+    kp_anchor = [8, 5, 2, 1, 4, 7, 21, 19, 17, 16, 18, 20, 12, 15, 15, 15, 15, 15, 15]
+    for k in range(NUM_KP):
+        c = _REST_JOINTS[kp_anchor[k]] + g.normal(0, 0.02, 3)
+        idx = np.argsort(((v_template - c) ** 2).sum(1))[:24]
+        w = g.random(24) + 0.1
+        cocoplus[k, idx] = w / w.sum()
+
+    kintree = np.stack([SMPL_PARENTS.astype(np.int64) % (2**32), np.arange(J)]).astype(np.uint32)
+    return {
+        "v_template": v_template.astype(np.float32),
+        "shapedirs": shapedirs.astype(np.float32),
+        "posedirs": posedirs.astype(np.float32),
+        "J_regressor": J_regressor.astype(np.float32),
+        "weights": weights.astype(np.float32),
+        "cocoplus_regressor": cocoplus.astype(np.float32),
+        "kintree_table": kintree,
+    }
+
+
+def make_mean_params(seed=5, zero=False):
+    """Stand-in for neutral_smpl_mean_params.h5: {'pose': [72], 'shape': [10]} (predictor.py:93-105)."""
+    g = _rng(seed)
+    if zero:
+        return {"pose": np.zeros(72, np.float64), "shape": np.zeros(10, np.float64)}
+    return {"pose": g.normal(0, 0.12, 72), "shape": g.normal(0, 0.4, 10)}
+
+
+def _trunc_normal(g, shape, std):
+    x = g.normal(0.0, 1.0, size=shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = g.normal(0.0, 1.0, size=int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * (std / 0.87962566103423978)).astype(np.float32)
+
+
+def make_encoder_params(seed=1, trivial_bn=False):
+    """Keras-layout ResNet-50 v1 parameters keyed '<layer>/<var>':
+    conv: kernel [KH,KW,Cin,Cout] (HWIO), bias [Cout]; BN: gamma, beta, moving_mean, moving_variance.
+    He-normal kernels (keras_applications resnet50.py uses he_normal); BN statistics are non-trivial
+    unless trivial_bn (gamma=1, beta=0, mean=0, var=1), so that BN folding is actually exercised.
+    The last BN of every bottleneck gets a small gamma so activations stay O(1) through 16 residual adds.
+    """
+    g = _rng(seed)
+    p = {}
+    for s in CONV_SPECS:
+        fan_in = s.kh * s.kw * s.cin
+        p[s.name + "/kernel"] = _trunc_normal(g, (s.kh, s.kw, s.cin, s.cout), math.sqrt(2.0 / fan_in))
+        if trivial_bn:
+            p[s.name + "/bias"] = np.zeros(s.cout, np.float32)
+            p[s.bn_name + "/gamma"] = np.ones(s.cout, np.float32)
+            p[s.bn_name + "/beta"] = np.zeros(s.cout, np.float32)
+            p[s.bn_name + "/moving_mean"] = np.zeros(s.cout, np.float32)
+            p[s.bn_name + "/moving_variance"] = np.ones(s.cout, np.float32)
+        else:
+            last = s.name.endswith("2c")
+            p[s.name + "/bias"] = g.normal(0, 0.02, s.cout).astype(np.float32)
+            lo, hi = (0.15, 0.45) if last else (0.6, 1.3)
+            p[s.bn_name + "/gamma"] = g.uniform(lo, hi, s.cout).astype(np.float32)
+            p[s.bn_name + "/beta"] = g.normal(0, 0.1, s.cout).astype(np.float32)
+            p[s.bn_name + "/moving_mean"] = g.normal(0, 0.1, s.cout).astype(np.float32)
+            p[s.bn_name + "/moving_variance"] = g.uniform(0.5, 1.5, s.cout).astype(np.float32)
+    return p
+
+
+def make_regressor_params(seed=2):
+    """Keras Dense layouts: dense_i/kernel [in,out], dense_i/bias [out]; glorot-uniform for the first
+    two, U(+-sqrt(0.06/1109)) for the last (reference: src/models.py:71-72)."""
+    g = _rng(seed)
+    dims = [(2133, 1024), (1024, 1024), (1024, 85)]
+    p = {}
+    for i, (fi, fo) in enumerate(dims):
+        lim = math.sqrt(6.0 / (fi + fo)) if i < 2 else math.sqrt(3.0 * 0.02 / (1024 + 85))
+        p["dense_%d/kernel" % i] = g.uniform(-lim, lim, (fi, fo)).astype(np.float32)
+        p["dense_%d/bias" % i] = g.normal(0, 0.01, fo).astype(np.float32)
+    return p
+
+
+def make_images(batch, seed=0, img_size=224):
+    """[B,224,224,3] float32 NHWC in [-1,1)."""
+    g = _rng(seed)
+    return (g.random((batch, img_size, img_size, 3), dtype=np.float32) * 2.0 - 1.0).astype(np.float32)
+
+
+def make_thetas(batch, seed=7, pose_std=0.35, shape_std=1.0):
+    """Plausible theta rows [s,tx,ty | 72 pose | 10 shape] for direct SMPL tests."""
+    g = _rng(seed)
+    th = np.zeros((batch, TOTAL_PARAMS), np.float64)
+    th[:, 0] = g.uniform(0.6, 1.2, batch)
+    th[:, 1:3] = g.normal(0, 0.1, (batch, 2))
+    th[:, 3:75] = g.normal(0, pose_std, (batch, 72))
+    th[:, 3] += math.pi
+    th[:, 75:] = g.normal(0, shape_std, (batch, 10))
+    return th.astype(np.float32)
+
+
+def make_lsp_targets(batch, seed=4, img_size=224):
+    """Config-5 style targets: seg_gts [B,224,224,1] in {0,1} (filled ellipse ~25 %
+    coverage), kp2d_gts [B,19,3] with xy in U[-1,1], vis~Bernoulli(0.8), rows 14-18 zero-filled
+    (reference: src/util/data_utils.py:34-56, src/data_loader.py:201-209)."""
+    g = _rng(seed)
+    yy, xx = np.mgrid[0:img_size, 0:img_size].astype(np.float32)
+    seg = np.zeros((batch, img_size, img_size, 1), np.float32)
+    for b in range(batch):
+        cx, cy = g.uniform(90, 134, 2)
+        rx, ry = g.uniform(35, 60), g.uniform(70, 100)
+        seg[b, :, :, 0] = (((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0).astype(np.float32)
+    kp = np.zeros((batch, NUM_KP, 3), np.float32)
+    kp[:, :14, :2] = g.uniform(-1, 1, (batch, 14, 2))
+    kp[:, :14, 2] = (g.random((batch, 14)) < 0.8).astype(np.float32)
+    return seg, kp

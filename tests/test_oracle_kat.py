@@ -1,0 +1,129 @@
+"""Closed-form known-answer tests that pin the CPU oracle.  The reference ships no
+tests/fixtures (F2), so these + the fp64 self-consistency run are what the oracle is pinned by
+("parity unpinned" w.r.t. the reference's own outputs)."""
+import math
+
+import numpy as np
+
+import hpe_amd
+from hpe_amd import resnet_spec, synthetic
+from oracle import hmr_oracle as O
+
+
+def test_rodrigues_zero_is_identity():
+    R = O.batch_rodrigues(np.zeros((3, 3), np.float32))
+    np.testing.assert_allclose(R, np.tile(np.eye(3, dtype=np.float32), (3, 1, 1)), atol=1e-7)
+
+
+def test_rodrigues_pi_about_x():
+    R = O.batch_rodrigues(np.array([[math.pi, 0, 0]], np.float32))
+    np.testing.assert_allclose(R[0], np.diag([1.0, -1.0, -1.0]), atol=2e-6)
+
+
+def test_rodrigues_is_rotation():
+    th = synthetic.make_thetas(16)[:, 3:75].reshape(-1, 3).astype(np.float64)
+    R = O.batch_rodrigues(th)
+    np.testing.assert_allclose(np.matmul(R, R.transpose(0, 2, 1)), np.tile(np.eye(3), (len(R), 1, 1)), atol=2e-7)  # r = theta/||theta+1e-8|| is unit only to ~1e-8 (the quirk)
+    np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=2e-7)
+
+
+def test_skew_layout():
+    S = O.batch_skew(np.array([[1.0, 2.0, 3.0]], np.float32))[0]
+    np.testing.assert_array_equal(S, np.array([[0, -3, 2], [3, 0, -1], [-2, 1, 0]], np.float32))
+
+
+def test_smpl_rest_pose(smpl_model):
+    sm = O.SMPL(smpl_model, dtype=np.float64)
+    verts, joints, Rs = sm(np.zeros((2, 10)), np.zeros((2, 72)), get_skin=True)
+    np.testing.assert_allclose(verts[0], smpl_model["v_template"].astype(np.float64), atol=1e-6)
+    J0 = smpl_model["J_regressor"].astype(np.float64) @ smpl_model["v_template"].astype(np.float64)
+    np.testing.assert_allclose(sm.J_transformed[1], J0, atol=1e-6)
+    np.testing.assert_allclose(joints[0], smpl_model["cocoplus_regressor"].astype(np.float64) @ verts[0], atol=1e-9)
+
+
+def test_smpl_global_rotation_only(smpl_model):
+    sm = O.SMPL(smpl_model, dtype=np.float64)
+    theta = np.zeros((1, 72))
+    theta[0, :3] = [0.3, -0.7, 0.2]
+    verts, _, Rs = sm(np.zeros((1, 10)), theta, get_skin=True)
+    R0 = Rs[0, 0]
+    vt = smpl_model["v_template"].astype(np.float64)
+    J0 = smpl_model["J_regressor"].astype(np.float64)[0] @ vt
+    # posedirs see (R_j - I) of joints 1..23 only -> zero here; every joint gets the root transform
+    np.testing.assert_allclose(verts[0], (vt - J0) @ R0.T + J0, atol=2e-6)
+
+
+def test_lbs_partition_of_unity(smpl_model):
+    assert np.allclose(smpl_model["weights"].sum(1), 1.0, atol=1e-6)
+    assert np.allclose(smpl_model["J_regressor"].sum(1), 1.0, atol=1e-5)
+    assert (smpl_model["weights"] >= 0).all()
+    par = smpl_model["kintree_table"][0].astype(np.int32)
+    assert par[0] == -1 and (par[1:] < np.arange(1, 24)).all()
+
+
+def test_projection_closed_form():
+    X = np.arange(2 * 5 * 3, dtype=np.float32).reshape(2, 5, 3) * 0.1
+    cam = np.array([[0.9, 0.1, -0.2], [1.1, 0.0, 0.3]], np.float32)
+    out = O.batch_orth_proj_idrot(X, cam)
+    np.testing.assert_allclose(out, cam[:, None, :1] * (X[:, :, :2] + cam[:, None, 1:]), rtol=1e-6)
+    px = O.reproject_vertices(X, np.array([[1.0, 0, 0], [1.0, 0, 0]], np.float32), np.array([224.0, 224.0], np.float32))
+    Xe = np.zeros((2, 2, 3), np.float32)
+    Xe[:, 0, :2] = -1
+    Xe[:, 1, :2] = 1
+    pe = O.reproject_vertices(Xe, np.array([[1.0, 0, 0], [1.0, 0, 0]], np.float32), np.array([224.0, 224.0], np.float32))
+    np.testing.assert_allclose(pe[:, 0], 0.0)
+    np.testing.assert_allclose(pe[:, 1], 224.0)
+    assert px.shape == (2, 5, 2)
+
+
+def test_kp_loss_closed_form():
+    gt = np.zeros((1, 19, 3), np.float32)
+    pred = np.ones((1, 19, 2), np.float32)
+    assert O.kp_reprojection_loss(gt, pred) == 0.0  # nothing visible
+    gt[0, 4] = [0.5, -0.25, 1.0]
+    pred[0, 4] = [0.5 + 0.3, -0.25 - 0.1]
+    np.testing.assert_allclose(O.kp_reprojection_loss(gt, pred), (0.3 + 0.1) / 2, rtol=1e-6)
+
+
+def test_bidirectional_dist_closed_form():
+    A = np.array([[1.0, 2.0], [3.0, 4.0], [0.0, 9.0]], np.float32)
+    assert O.bidirectional_dist(A, A.copy()) == 0.0
+    a = np.array([[1.0, 1.0]], np.float32)
+    b = np.array([[4.0, 5.0]], np.float32)
+    np.testing.assert_allclose(O.bidirectional_dist(a, b), 5.0 + 7.0)
+    # denominator quirk: 3 + 6890
+    sil_gt = np.array([[0, 1.0, 1.0]], np.float32)  # (b, y, x)
+    pred = np.tile(b[None], (1, 6890, 1)).astype(np.float32)
+    np.testing.assert_allclose(O.mesh_reprojection_loss(sil_gt, pred, 1), (6890 * 5.0 + 7.0) / 6893.0, rtol=1e-6)
+
+
+def test_encoder_inventory():
+    assert len(resnet_spec.CONV_SPECS) == 53
+    assert resnet_spec.encoder_param_count() == 23587712
+    assert resnet_spec.encoder_macs_per_image() == 3855925248
+    n3 = sum(1 for s in resnet_spec.CONV_SPECS if s.kh == 3)
+    n1s2 = sum(1 for s in resnet_spec.CONV_SPECS if s.kh == 1 and s.stride == 2)
+    assert (n3, n1s2) == (16, 6)  # 3 blocks x (2a + shortcut) have stride 2
+
+
+def test_mean_param_layout():
+    mean = O.load_mean_param(synthetic.make_mean_params(zero=True))
+    exp = np.zeros((1, 85), np.float32)
+    exp[0, 0] = 0.9
+    exp[0, 3] = math.pi
+    np.testing.assert_array_equal(mean, exp)
+
+
+def test_regressor_shapes_and_init():
+    p = synthetic.make_regressor_params()
+    assert p["dense_0/kernel"].shape == (2133, 1024) and p["dense_2/kernel"].shape == (1024, 85)
+    assert abs(np.abs(p["dense_2/kernel"]).max() - math.sqrt(0.06 / 1109)) < 1e-4
+    assert sum(v.size for v in p.values()) == 3321941
+
+
+def test_fp32_oracle_close_to_fp64(smpl_model):
+    th = synthetic.make_thetas(4)
+    v32, j32, _ = O.SMPL(smpl_model, dtype=np.float32)(th[:, 75:], th[:, 3:75], get_skin=True)
+    v64, j64, _ = O.SMPL(smpl_model, dtype=np.float64)(th[:, 75:], th[:, 3:75], get_skin=True)
+    assert np.abs(v32 - v64).max() / np.abs(v64).max() < 5e-6
+    assert np.abs(j32 - j64).max() / np.abs(j64).max() < 5e-6
