@@ -1,0 +1,262 @@
+// conv_gemm.hip -- fp32 implicit-GEMM convolution / dense layer on the gfx950 matrix cores.
+//
+// Computes  Y[m][n] = act( (sum_k A[m][k] * Wt[n][k]) * scale[n] + shift[n] + R[m][n] )
+//   m : output pixel (b, ho, wo) flattened (NHWC)            -- or the image index for Dense layers
+//   n : output channel
+//   k : (kh, kw, cin) flattened with cin fastest (NHWC / HWIO order)
+// which covers every conv of the Keras ResNet-50 v1 the reference instantiates
+// (reference: src/models.py:35-41) with BatchNorm folded into (scale, shift), the residual add + ReLU of
+// the bottleneck fused in the epilogue, and the three Dense layers of RegressionNetwork
+// (reference: src/models.py:60-74; y = x @ kernel + bias is the scale == 1 case).
+//
+// CDNA4 mapping
+//   * v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (64 FLOP/clk/SIMD = the fp32 roofline, 157.3 TF).
+//     Lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31].
+//   * A (activations) and W (weights, pre-packed [n][k] on the host at load time) are both staged in LDS
+//     as [row][32 k] slabs with a 36-float row pitch: one ds_read_b128 per lane then feeds FOUR MFMAs
+//     (lanes 0-31 hold k = 8g..8g+3, lanes 32-63 hold k = 8g+4..8g+7 -- k is only a summation label,
+//     A and B use the same labelling) and the pitch makes the 16-lane b128 groups conflict-free.
+//   * global->LDS is register staged (16 B/lane, a full 128-B line per 8 lanes) and double buffered:
+//     the loads of slab s+1 are in flight while slab s is multiplied; one barrier per slab.
+//   * 64-wide waves in a WM x WN grid, each wave owns an (MT*32) x (NT*32) accumulator block.
+//   * blockIdx -> tile mapping is XCD-aware: the N-tiles that share an A row-panel are consecutive
+//     on ONE XCD (blocks b, b+8, ... share an L2), so the panel is fetched from HBM once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hpe_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BK 32
+#define LDS_PITCH 36  // floats; 144 B row pitch -> conflict-free ds_read_b128 (see header comment)
+
+namespace {
+
+template <int MODE>
+struct RowAddr {
+    int base;    // element offset of this row's first k element (see per-mode meaning)
+    int ho, wo;  // only CONV3
+};
+
+template <int MODE>
+__device__ __forceinline__ RowAddr<MODE> make_row(const GemmArgs& p, int m, int kc4) {
+    RowAddr<MODE> r;
+    r.ho = 0;
+    r.wo = 0;
+    if (m >= p.M) m = p.M - 1;  // tail rows: read a valid row, the store guard drops the result
+    if (MODE == GEMM_DENSE) {
+        r.base = m * p.lda + kc4;
+    } else {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        if (MODE == GEMM_STRIDED) {
+            r.base = ((b * p.Hi + ho * p.stride) * p.Wi + wo * p.stride) * p.Cin + kc4;
+        } else if (MODE == GEMM_CONV3) {
+            r.base = ((b * p.Hi + ho) * p.Wi + wo) * p.Cin + kc4;
+            r.ho = ho;
+            r.wo = wo;
+        } else {  // GEMM_STEM: padded input [B,Hi,Wi,4], 8 pixels x 4 ch = one 32-float slab per kh
+            r.base = ((b * p.Hi + 2 * ho) * p.Wi + 2 * wo) * 4 + kc4;
+        }
+    }
+    return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const RowAddr<MODE>& r, int slab) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
+        return *reinterpret_cast<const f32x4*>(p.x + (size_t)(r.base + slab * BK));
+    } else if (MODE == GEMM_CONV3) {
+        const int tap = slab / p.cin_slabs;
+        const int c0 = (slab - tap * p.cin_slabs) * BK;
+        const int kh = tap / 3;
+        const int dh = kh - 1;
+        const int dw = tap - kh * 3 - 1;
+        const bool ok = (unsigned)(r.ho + dh) < (unsigned)p.Hi && (unsigned)(r.wo + dw) < (unsigned)p.Wi;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(r.base + (dh * p.Wi + dw) * p.Cin + c0));
+        return v;
+    } else {
+        return *reinterpret_cast<const f32x4*>(p.x + (size_t)(r.base + slab * p.Wi * 4));
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int AP = BM / 32;  // A rows staged per thread
+    constexpr int BP = BN / 32;  // W rows staged per thread
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(MT >= 1 && NT >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_PITCH];
+
+    // XCD-aware bijective remap: blocks b, b+8, ... (one XCD) walk consecutive tiles.
+    const int total = p.n_mtiles * p.n_ntiles;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int mtile = swz / p.n_ntiles;
+    const int ntile = swz - mtile * p.n_ntiles;
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+
+    // ---- staging addresses: thread t stages 16 B (k chunk t&7) of rows (t>>3) + 32*i
+    const int kc4 = (t & 7) * 4;
+    const int srow = t >> 3;
+    RowAddr<MODE> arow[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) arow[i] = make_row<MODE>(p, m0 + srow + 32 * i, kc4);
+    const float* wptr = p.w + (size_t)(n0 + srow) * p.ldw + kc4;
+    const int lds_st = srow * LDS_PITCH + kc4;
+
+    // ---- fragment read offsets (floats) inside a buffer
+    const int frag = (lane & 31) * LDS_PITCH + 4 * (lane >> 5);
+    const int a_off = (wm * MT * 32) * LDS_PITCH + frag;
+    const int b_off = (BM + wn * NT * 32) * LDS_PITCH + frag;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[AP], rb[BP];
+    const int S = p.K / BK;
+
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], 0);
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[0][lds_st + 32 * i * LDS_PITCH]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[0][lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
+    __syncthreads();
+
+    for (int s = 0; s < S; ++s) {
+        const int cur = s & 1;
+        const bool more = (s + 1) < S;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], s + 1);
+#pragma unroll
+            for (int i = 0; i < BP; ++i)
+                rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw + (s + 1) * BK);
+        }
+        const float* A = &lds[cur][a_off];
+        const float* B = &lds[cur][b_off];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_PITCH + g * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDS_PITCH + g * 8);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[nxt][lds_st + 32 * i * LDS_PITCH]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < BP; ++i)
+                *reinterpret_cast<f32x4*>(&lds[nxt][lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int col_l = lane & 31;
+    const int row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + (wn * NT + j) * 32 + col_l;
+        const bool n_ok = n < p.N;
+        const float sc = n_ok ? p.scale[n] : 0.f;
+        const float sh = n_ok ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + (wm * MT + i) * 32 + row_l;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (n_ok && m < p.M) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (p.res) v += p.res[(size_t)m * p.ldres + n];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[(size_t)m * p.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
+    p.n_mtiles = (p.M + BM - 1) / BM;
+    p.n_ntiles = (p.N + BN - 1) / BN;
+    const int grid = p.n_mtiles * p.n_ntiles;
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_mode(GemmArgs& p, int tile, hipStream_t st) {
+    switch (tile) {
+        case TILE_128x128: return launch_cfg<MODE, 128, 128, 2, 2>(p, st);
+        case TILE_128x64: return launch_cfg<MODE, 128, 64, 2, 2>(p, st);
+        case TILE_64x64: return launch_cfg<MODE, 64, 64, 2, 2>(p, st);
+        case TILE_64x128: return launch_cfg<MODE, 64, 128, 2, 2>(p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// Host-side shape contract (checked here so a bad plan cannot fault on the device).
+hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.ldw % 4) != 0 || p.ldw < p.K) return hipErrorInvalidValue;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return hipErrorInvalidValue;
+    const int bn = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : 64;
+    const int n_pad = ((p.N + bn - 1) / bn) * bn;
+    if (n_pad > p.w_rows) return hipErrorInvalidValue;  // packed weights must cover the padded N tiles
+    switch (mode) {
+        case GEMM_DENSE:
+            if (p.lda < p.K || (p.lda % 4) != 0) return hipErrorInvalidValue;
+            return launch_mode<GEMM_DENSE>(p, tile, st);
+        case GEMM_STRIDED:
+            if (p.Cin != p.K || (p.Cin % 4) != 0) return hipErrorInvalidValue;
+            if ((p.Ho - 1) * p.stride >= p.Hi || (p.Wo - 1) * p.stride >= p.Wi) return hipErrorInvalidValue;
+            return launch_mode<GEMM_STRIDED>(p, tile, st);
+        case GEMM_CONV3:
+            if ((p.Cin % BK) != 0 || p.K != 9 * p.Cin || p.cin_slabs != p.Cin / BK || p.Ho != p.Hi || p.Wo != p.Wi)
+                return hipErrorInvalidValue;
+            return launch_mode<GEMM_CONV3>(p, tile, st);
+        case GEMM_STEM:
+            if (p.K != 7 * BK || p.Hi < 2 * (p.Ho - 1) + 7 || p.Wi < 2 * (p.Wo - 1) + 8) return hipErrorInvalidValue;
+            return launch_mode<GEMM_STEM>(p, tile, st);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,133 @@
+// encoder_ops.hip -- the HBM-bound glue ops of the ResNet-50 v1 encoder (reference: src/models.py:35-41 ->
+// keras.applications.ResNet50): conv1_pad ZeroPadding2D(3) (+ channel pad 3->4 so that one 7-tap kernel
+// row is 8 px * 4 ch = one contiguous 32-float GEMM slab), pool1_pad ZeroPadding2D(1) + MaxPooling2D(3,2),
+// and the final GlobalAveragePooling2D.  All are 16 B/lane coalesced NHWC streams.
+#include <hip/hip_runtime.h>
+
+#include "hpe_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// img [B,H,W,3] -> out [B,Hp,Wp,4]; out(b, y+3, x+3, c<3) = img(b,y,x,c); everything else 0.
+__global__ void pad_input_kernel(const float* __restrict__ img, f32x4* __restrict__ out, int B, int H, int W, int Hp, int Wp) {
+    const long total = (long)B * Hp * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const long r = i / Wp;
+        const int yp = (int)(r % Hp);
+        const int b = (int)(r / Hp);
+        const int x = xp - 3, y = yp - 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const float* s = img + (((long)b * H + y) * W + x) * 3;
+            v.x = s[0];
+            v.y = s[1];
+            v.z = s[2];
+        }
+        out[i] = v;
+    }
+}
+
+// x [B,H,H,C] (post-ReLU conv1) -> y [B,H/2,H/2,C]: zero pad 1 (the pad value takes part in the max,
+// exactly as ZeroPadding2D + 'valid' MaxPooling2D does), 3x3 window, stride 2.
+__global__ void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int B, int H, int C4) {
+    const int Ho = H / 2;
+    const long total = (long)B * Ho * Ho * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long r = i / C4;
+        const int wo = (int)(r % Ho);
+        r /= Ho;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        f32x4 m = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * ho - 1 + dy;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * wo - 1 + dx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H) v = x[(((long)b * H + yy) * H + xx) * C4 + c];
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        }
+        y[i] = m;
+    }
+}
+
+// x [B,HW,C] -> y [B, ldy] (first C columns): mean over HW.
+__global__ void avgpool_kernel(const f32x4* __restrict__ x, float* __restrict__ y, int B, int HW, int C4, int ldy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C4) return;
+    const int c = i % C4;
+    const int b = i / C4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* p = x + (long)b * HW * C4 + c;
+    for (int k = 0; k < HW; ++k) s += p[(long)k * C4];
+    const float inv = 1.0f / (float)HW;
+    f32x4 o = s * inv;
+    *reinterpret_cast<f32x4*>(y + (long)b * ldy + c * 4) = o;
+}
+
+// theta[b][0..84] = mean[0..84]  (tf.tile(mean_var, [B,1]); reference: src/predictor.py:126)
+__global__ void tile_theta_kernel(const float* __restrict__ mean, float* __restrict__ theta, int B, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 85) return;
+    const int b = i / 85, k = i - b * 85;
+    theta[(long)b * ld + k] = mean[k];
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int B, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n) return;
+    const int b = i / n, k = i - b * n;
+    dst[(long)b * ldd + k] = src[(long)b * lds + k];
+}
+
+inline int grid_for(long total, int block, int cap = 256 * 8) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+hipError_t hpe_launch_pad_input(const float* img, float* out, int B, int H, int W, int Hp, int Wp, hipStream_t st) {
+    const long total = (long)B * Hp * Wp;
+    hipLaunchKernelGGL(pad_input_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, img, reinterpret_cast<f32x4*>(out), B, H,
+                       W, Hp, Wp);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_maxpool(const float* x, float* y, int B, int H, int C, hipStream_t st) {
+    if ((C % 4) != 0 || (H % 2) != 0) return hipErrorInvalidValue;
+    const long total = (long)B * (H / 2) * (H / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<f32x4*>(y), B, H, C / 4);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_avgpool(const float* x, float* y, int B, int HW, int C, int ldy, hipStream_t st) {
+    if ((C % 4) != 0 || (ldy % 4) != 0) return hipErrorInvalidValue;
+    const int total = B * (C / 4);
+    hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), y, B, HW,
+                       C / 4, ldy);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_tile_theta(const float* mean85, float* theta, int B, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(tile_theta_kernel, dim3((B * 85 + 255) / 256), dim3(256), 0, st, mean85, theta, B, ld);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_copy_theta(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((B * n + 255) / 256), dim3(256), 0, st, src, lds, dst, ldd, B, n);
+    return hipGetLastError();
+}

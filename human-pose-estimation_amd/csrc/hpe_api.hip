@@ -1,0 +1,769 @@
+// hpe_api.hip -- the C ABI of include/hpe.h: context, weight ingestion (Keras layouts), plan and dispatch.
+// Host logic only; the kernels live in conv_gemm.hip / encoder_ops.hip / smpl.hip / losses.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hpe.h"
+#include "hpe_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                             \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return fail(HPE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +      \
+                                         std::to_string(__LINE__) + ")");                                         \
+    } while (0)
+
+struct ConvSpec {
+    char name[24];
+    char bn[24];
+    int kh, kw, cin, cout, stride, hin, hout;
+};
+
+// ResNet-50 v1 layer table, Keras names / order [2a, 2b, 2c, (1)] per block.
+std::vector<ConvSpec> build_specs() {
+    std::vector<ConvSpec> v;
+    auto add = [&](const std::string& n, const std::string& b, int kh, int cin, int cout, int s, int hin, int hout) {
+        ConvSpec c;
+        snprintf(c.name, sizeof c.name, "%s", n.c_str());
+        snprintf(c.bn, sizeof c.bn, "%s", b.c_str());
+        c.kh = c.kw = kh;
+        c.cin = cin;
+        c.cout = cout;
+        c.stride = s;
+        c.hin = hin;
+        c.hout = hout;
+        v.push_back(c);
+    };
+    add("conv1", "bn_conv1", 7, 3, 64, 2, 224, 112);
+    const int nblk[4] = {3, 4, 6, 3};
+    const int filt[4][3] = {{64, 64, 256}, {128, 128, 512}, {256, 256, 1024}, {512, 512, 2048}};
+    int cin = 64, h = 56;
+    for (int st = 0; st < 4; ++st) {
+        for (int b = 0; b < nblk[st]; ++b) {
+            const bool first = b == 0;
+            const int s = (first && st > 0) ? 2 : 1;
+            const int hout = h / s;
+            char base[24], bn[24];
+            snprintf(base, sizeof base, "res%d%c_branch", st + 2, 'a' + b);
+            snprintf(bn, sizeof bn, "bn%d%c_branch", st + 2, 'a' + b);
+            add(std::string(base) + "2a", std::string(bn) + "2a", 1, cin, filt[st][0], s, h, hout);
+            add(std::string(base) + "2b", std::string(bn) + "2b", 3, filt[st][0], filt[st][1], 1, hout, hout);
+            add(std::string(base) + "2c", std::string(bn) + "2c", 1, filt[st][1], filt[st][2], 1, hout, hout);
+            if (first) add(std::string(base) + "1", std::string(bn) + "1", 1, cin, filt[st][2], s, h, hout);
+            cin = filt[st][2];
+            h = hout;
+        }
+    }
+    return v;
+}
+
+const std::vector<ConvSpec>& specs() {
+    static const std::vector<ConvSpec> s = build_specs();
+    return s;
+}
+
+inline int round_up(int x, int m) { return ((x + m - 1) / m) * m; }
+
+struct ConvLayer {
+    std::vector<float> kernel, bias, gamma, beta, mean, var;  // host staging (Keras layouts)
+    bool loaded = false;
+    float* w = nullptr;  // device, packed [n_pad][k_pad]
+    float* scale = nullptr;
+    float* shift = nullptr;
+    int n_pad = 0, k_pad = 0;
+};
+
+struct DenseLayer {
+    std::vector<float> kernel, bias;
+    bool loaded = false;
+};
+
+constexpr int STEM_HP = 230;  // 224 + 2*3
+constexpr int STEM_WP = 232;  // 224 + 2*3 + 2 (8th tap column of the last window, zero weights)
+constexpr int THETA_LD = 96;  // theta rows padded to 3 k-slabs of 32
+
+}  // namespace
+
+struct hpe_ctx {
+    HpeConfig cfg{};
+    bool finalized = false;
+    bool have_encoder = false, have_regressor = false, have_smpl = false;
+    ConvLayer conv[HPE_NUM_CONV];
+    DenseLayer dense[HPE_NUM_DENSE];
+    // SMPL host staging
+    bool smpl_loaded = false, mean_loaded = false;
+    std::vector<float> h_vt, h_sd, h_pd, h_jreg, h_w, h_kreg;
+    std::vector<int> h_par;
+    int num_kp = 19;
+    float h_mean[HPE_THETA_DIM];
+    // device: regressor
+    float *w1f = nullptr, *w1t = nullptr, *w2 = nullptr, *w3 = nullptr, *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
+    float *ones = nullptr, *zeros = nullptr, *mean_dev = nullptr;
+    // device: SMPL
+    SmplDev smpl{};
+    SmplWork work{};
+    float* smpl_basis_src = nullptr;  // [11][V*3]: v_template | shapedirs^T
+    // device: activations
+    float *padded = nullptr, *X0 = nullptr, *X1 = nullptr, *T1 = nullptr, *T2 = nullptr, *SC = nullptr;
+    float *feat = nullptr, *P1 = nullptr, *H1 = nullptr, *H2 = nullptr, *thA = nullptr, *thB = nullptr;
+    float* loss_ws = nullptr;
+    size_t loss_ws_floats = 0;
+    std::vector<void*> allocs;
+    // timing
+    int timing = 0;
+    hipEvent_t ev[8]{};
+    hipEvent_t cev0[HPE_NUM_CONV]{}, cev1[HPE_NUM_CONV]{};
+    bool ev_ok = false, timed_valid = false, conv_timed_valid = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+int dev_alloc(hpe_ctx* c, float** p, size_t n_floats, bool zero) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, n_floats * sizeof(float)));
+    c->allocs.push_back(q);
+    if (zero) HIP_TRY(hipMemset(q, 0, n_floats * sizeof(float)));
+    *p = static_cast<float*>(q);
+    return HPE_OK;
+}
+
+int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
+    int rc = dev_alloc(c, p, h.size(), false);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return HPE_OK;
+}
+
+int pick_tile(int M, int N) {
+    // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
+    const bool wide = N > 64;
+    struct Cand {
+        int tile, bm, bn;
+    };
+    const Cand wide_c[] = {{TILE_128x128, 128, 128}, {TILE_64x128, 64, 128}, {TILE_64x64, 64, 64}};
+    const Cand narrow_c[] = {{TILE_128x64, 128, 64}, {TILE_64x64, 64, 64}};
+    const Cand* cs = wide ? wide_c : narrow_c;
+    const int nc = wide ? 3 : 2;
+    for (int i = 0; i < nc; ++i) {
+        const long tiles = (long)((M + cs[i].bm - 1) / cs[i].bm) * ((N + cs[i].bn - 1) / cs[i].bn);
+        if (tiles >= 512 || i == nc - 1) return cs[i].tile;
+    }
+    return TILE_64x64;
+}
+
+#define HIPE(expr)                               \
+    do {                                         \
+        hipError_t _e = (expr);                  \
+        if (_e != hipSuccess) return _e;         \
+    } while (0)
+
+// one conv layer (+BN fold, +residual, +ReLU) through the implicit-GEMM kernel
+hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st) {
+    const ConvSpec& s = specs()[idx];
+    const ConvLayer& L = c->conv[idx];
+    GemmArgs p{};
+    p.x = x;
+    p.w = L.w;
+    p.scale = L.scale;
+    p.shift = L.shift;
+    p.res = res;
+    p.y = y;
+    p.M = B * s.hout * s.hout;
+    p.N = s.cout;
+    p.K = L.k_pad;
+    p.ldw = L.k_pad;
+    p.w_rows = L.n_pad;
+    p.ldy = s.cout;
+    p.ldres = s.cout;
+    p.relu = relu;
+    p.Hi = p.Wi = s.hin;
+    p.Cin = s.cin;
+    p.Ho = p.Wo = s.hout;
+    p.stride = s.stride;
+    p.cin_slabs = s.cin / 32;
+    p.lda = s.cin;
+    int mode;
+    if (idx == 0) {
+        mode = GEMM_STEM;
+        p.Hi = STEM_HP;
+        p.Wi = STEM_WP;
+        p.Cin = 4;
+    } else if (s.kh == 3) {
+        mode = GEMM_CONV3;
+    } else if (s.stride == 1) {
+        mode = GEMM_DENSE;
+    } else {
+        mode = GEMM_STRIDED;
+    }
+    return hpe_launch_gemm(p, mode, pick_tile(p.M, p.N), st);
+}
+
+hipError_t run_dense(const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
+                     const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
+    GemmArgs p{};
+    p.x = x;
+    p.w = w;
+    p.scale = scale;
+    p.shift = shift;
+    p.res = res;
+    p.y = y;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.lda = lda;
+    p.ldw = K;
+    p.w_rows = w_rows;
+    p.ldy = ldy;
+    p.ldres = ldres;
+    p.relu = relu;
+    return hpe_launch_gemm(p, GEMM_DENSE, TILE_64x64, st);
+}
+
+hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st) {
+    const bool t2 = c->timing >= 2;
+    if (t2) HIPE(hipEventRecord(c->cev0[idx], st));
+    HIPE(run_conv(c, idx, x, B, res, relu, y, st));
+    if (t2) HIPE(hipEventRecord(c->cev1[idx], st));
+    return hipSuccess;
+}
+
+hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
+    HIPE(hpe_launch_pad_input(images, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
+    HIPE(timed_conv(c, 0, c->padded, B, nullptr, 1, c->SC, st));
+    HIPE(hpe_launch_maxpool(c->SC, c->X0, B, 112, 64, st));
+    float* cur = c->X0;
+    float* nxt = c->X1;
+    int ci = 1;
+    const int nblk[4] = {3, 4, 6, 3};
+    for (int stg = 0; stg < 4; ++stg) {
+        for (int b = 0; b < nblk[stg]; ++b) {
+            const bool first = b == 0;
+            const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
+            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, c->T1, st));
+            HIPE(timed_conv(c, i2b, c->T1, B, nullptr, 1, c->T2, st));
+            const float* res = cur;
+            if (first) {
+                // projection shortcut (conv_block), no ReLU before the add
+                HIPE(timed_conv(c, i1, cur, B, nullptr, 0, c->SC, st));
+                res = c->SC;
+            }
+            HIPE(timed_conv(c, i2c, c->T2, B, res, 1, nxt, st));
+            ci += first ? 4 : 3;
+            float* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+    }
+    return hpe_launch_avgpool(cur, features, B, 49, HPE_FEATURE_DIM, ldfeat, st);
+}
+
+// one IEF step on padded theta rows [B, THETA_LD]; P1 = features . W1[:2048] must be current
+hipError_t regress_impl(hpe_ctx* c, const float* th_prev, float* th_next, int B, hipStream_t st) {
+    HIPE(run_dense(th_prev, THETA_LD, B, THETA_LD, c->w1t, 1024, 1024, c->ones, c->b1, c->P1, 1024, 1, c->H1, 1024, st));
+    HIPE(run_dense(c->H1, 1024, B, 1024, c->w2, 1024, 1024, c->ones, c->b2, nullptr, 0, 1, c->H2, 1024, st));
+    return run_dense(c->H2, 1024, B, 1024, c->w3, 128, HPE_THETA_DIM, c->ones, c->b3, th_prev, THETA_LD, 0, th_next, THETA_LD, st);
+}
+
+hipError_t features_proj(hpe_ctx* c, const float* features, int B, hipStream_t st) {
+    return run_dense(features, HPE_FEATURE_DIM, B, HPE_FEATURE_DIM, c->w1f, 1024, 1024, c->ones, c->zeros, nullptr, 0, 0, c->P1,
+                     1024, st);
+}
+
+enum { NEED_ENC = 1, NEED_REG = 2, NEED_SMPL = 4 };
+
+int check_ready(hpe_ctx* c, int B, int need) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    if (!c->finalized) return fail(HPE_ERR_STATE, "hpe_finalize() has not been called");
+    if (B < 1 || B > c->cfg.max_batch) return fail(HPE_ERR_INVALID, "batch " + std::to_string(B) + " outside [1, max_batch]");
+    if ((need & NEED_ENC) && !c->have_encoder) return fail(HPE_ERR_STATE, "encoder weights were not loaded before hpe_finalize");
+    if ((need & NEED_REG) && !c->have_regressor) return fail(HPE_ERR_STATE, "regressor weights / mean theta were not loaded");
+    if ((need & NEED_SMPL) && !c->have_smpl) return fail(HPE_ERR_STATE, "SMPL model was not loaded before hpe_finalize");
+    return HPE_OK;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* hpe_last_error(void) { return g_err.c_str(); }
+const char* hpe_version(void) { return "hpe_hip 0.1 (gfx950)"; }
+
+const char* hpe_conv_layer_name(int idx) { return (idx >= 0 && idx < HPE_NUM_CONV) ? specs()[idx].name : nullptr; }
+const char* hpe_bn_layer_name(int idx) { return (idx >= 0 && idx < HPE_NUM_CONV) ? specs()[idx].bn : nullptr; }
+
+int hpe_conv_layer_geometry(int idx, int out[7]) {
+    if (idx < 0 || idx >= HPE_NUM_CONV || !out) return fail(HPE_ERR_INVALID, "bad conv index");
+    const ConvSpec& s = specs()[idx];
+    out[0] = s.kh;
+    out[1] = s.kw;
+    out[2] = s.cin;
+    out[3] = s.cout;
+    out[4] = s.stride;
+    out[5] = s.hin;
+    out[6] = s.hout;
+    return HPE_OK;
+}
+
+int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
+    if (!cfg || !out) return fail(HPE_ERR_INVALID, "null argument");
+    if (cfg->max_batch < 1 || cfg->max_batch > 1024) return fail(HPE_ERR_INVALID, "max_batch must be in [1,1024]");
+    if (cfg->num_stage < 1 || cfg->num_stage > 16) return fail(HPE_ERR_INVALID, "num_stage must be in [1,16]");
+    if (cfg->encoder_dtype != 0) return fail(HPE_ERR_INVALID, "encoder_dtype: only 0 (fp32) is implemented");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(HPE_ERR_NO_DEVICE, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(HPE_ERR_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HPE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    hpe_ctx* c = new hpe_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
+    *out = c;
+    return HPE_OK;
+}
+
+int hpe_destroy(hpe_ctx* c) {
+    if (!c) return HPE_OK;
+    DeviceGuard g(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->ev_ok) {
+        for (auto& e : c->ev) (void)hipEventDestroy(e);
+        for (auto& e : c->cev0) (void)hipEventDestroy(e);
+        for (auto& e : c->cev1) (void)hipEventDestroy(e);
+    }
+    delete c;
+    return HPE_OK;
+}
+
+int hpe_load_smpl(hpe_ctx* c, const HpeSmplModel* m) {
+    if (!c || !m) return fail(HPE_ERR_INVALID, "null argument");
+    if (c->finalized) return fail(HPE_ERR_STATE, "already finalized");
+    if (!m->v_template || !m->shapedirs || !m->posedirs || !m->J_regressor || !m->weights || !m->kp_regressor || !m->parents)
+        return fail(HPE_ERR_INVALID, "null SMPL array");
+    if (m->num_kp < 1 || m->num_kp > HPE_MAX_KP) return fail(HPE_ERR_INVALID, "num_kp must be in [1,24]");
+    if (m->parents[0] >= 0) return fail(HPE_ERR_INVALID, "parents[0] must be negative (root)");
+    for (int i = 1; i < 24; ++i)
+        if (m->parents[i] < 0 || m->parents[i] >= i) return fail(HPE_ERR_INVALID, "parents[i] must satisfy 0 <= parents[i] < i");
+    const int V = HPE_NUM_VERTS;
+    c->h_vt.assign(m->v_template, m->v_template + V * 3);
+    c->h_sd.assign(m->shapedirs, m->shapedirs + (size_t)V * 3 * 10);
+    c->h_pd.assign(m->posedirs, m->posedirs + (size_t)V * 3 * 207);
+    c->h_jreg.assign(m->J_regressor, m->J_regressor + (size_t)24 * V);
+    c->h_w.assign(m->weights, m->weights + (size_t)V * 24);
+    c->h_kreg.assign(m->kp_regressor, m->kp_regressor + (size_t)m->num_kp * V);
+    c->h_par.assign(m->parents, m->parents + 24);
+    c->num_kp = m->num_kp;
+    c->smpl_loaded = true;
+    return HPE_OK;
+}
+
+int hpe_load_conv(hpe_ctx* c, int idx, const float* kernel, const float* bias, const float* gamma, const float* beta,
+                  const float* mean, const float* var) {
+    if (!c || idx < 0 || idx >= HPE_NUM_CONV) return fail(HPE_ERR_INVALID, "bad conv index");
+    if (c->finalized) return fail(HPE_ERR_STATE, "already finalized");
+    if (!kernel || !bias || !gamma || !beta || !mean || !var) return fail(HPE_ERR_INVALID, "null conv array");
+    const ConvSpec& s = specs()[idx];
+    ConvLayer& L = c->conv[idx];
+    L.kernel.assign(kernel, kernel + (size_t)s.kh * s.kw * s.cin * s.cout);
+    L.bias.assign(bias, bias + s.cout);
+    L.gamma.assign(gamma, gamma + s.cout);
+    L.beta.assign(beta, beta + s.cout);
+    L.mean.assign(mean, mean + s.cout);
+    L.var.assign(var, var + s.cout);
+    L.loaded = true;
+    return HPE_OK;
+}
+
+int hpe_load_dense(hpe_ctx* c, int idx, const float* kernel, const float* bias) {
+    if (!c || idx < 0 || idx >= HPE_NUM_DENSE) return fail(HPE_ERR_INVALID, "bad dense index");
+    if (c->finalized) return fail(HPE_ERR_STATE, "already finalized");
+    if (!kernel || !bias) return fail(HPE_ERR_INVALID, "null dense array");
+    const int din[3] = {2133, 1024, 1024}, dout[3] = {1024, 1024, 85};
+    c->dense[idx].kernel.assign(kernel, kernel + (size_t)din[idx] * dout[idx]);
+    c->dense[idx].bias.assign(bias, bias + dout[idx]);
+    c->dense[idx].loaded = true;
+    return HPE_OK;
+}
+
+int hpe_load_mean_theta(hpe_ctx* c, const float* mean85) {
+    if (!c || !mean85) return fail(HPE_ERR_INVALID, "null argument");
+    if (c->finalized) return fail(HPE_ERR_STATE, "already finalized");
+    memcpy(c->h_mean, mean85, sizeof(float) * HPE_THETA_DIM);
+    c->mean_loaded = true;
+    return HPE_OK;
+}
+
+int hpe_finalize(hpe_ctx* c) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    if (c->finalized) return fail(HPE_ERR_STATE, "already finalized");
+    {
+        int nconv = 0, ndense = 0;
+        for (int i = 0; i < HPE_NUM_CONV; ++i) nconv += c->conv[i].loaded ? 1 : 0;
+        for (int i = 0; i < HPE_NUM_DENSE; ++i) ndense += c->dense[i].loaded ? 1 : 0;
+        if (nconv != 0 && nconv != HPE_NUM_CONV) {
+            for (int i = 0; i < HPE_NUM_CONV; ++i)
+                if (!c->conv[i].loaded) return fail(HPE_ERR_STATE, std::string("conv layer not loaded: ") + specs()[i].name);
+        }
+        if (ndense != 0 && (ndense != HPE_NUM_DENSE || !c->mean_loaded))
+            return fail(HPE_ERR_STATE, "regressor needs all 3 dense layers and the mean theta");
+        c->have_encoder = nconv == HPE_NUM_CONV;
+        c->have_regressor = ndense == HPE_NUM_DENSE && c->mean_loaded;
+        c->have_smpl = c->smpl_loaded;
+        if (!c->have_encoder && !c->have_regressor && !c->have_smpl) return fail(HPE_ERR_STATE, "nothing was loaded");
+    }
+    DeviceGuard g(c->cfg.device);
+    int rc;
+    // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
+    for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {
+        const ConvSpec& s = specs()[i];
+        ConvLayer& L = c->conv[i];
+        L.n_pad = round_up(s.cout, 128);
+        L.k_pad = (i == 0) ? 7 * 32 : round_up(s.kh * s.kw * s.cin, 32);
+        std::vector<float> wt((size_t)L.n_pad * L.k_pad, 0.f);
+        for (int kh = 0; kh < s.kh; ++kh)
+            for (int kw = 0; kw < s.kw; ++kw)
+                for (int ci = 0; ci < s.cin; ++ci) {
+                    const int k = (i == 0) ? (kh * 32 + kw * 4 + ci) : ((kh * s.kw + kw) * s.cin + ci);
+                    const float* src = &L.kernel[(((size_t)kh * s.kw + kw) * s.cin + ci) * s.cout];
+                    for (int n = 0; n < s.cout; ++n) wt[(size_t)n * L.k_pad + k] = src[n];
+                }
+        std::vector<float> sc(s.cout), sh(s.cout);
+        for (int n = 0; n < s.cout; ++n) {
+            const double inv = (double)L.gamma[n] / std::sqrt((double)L.var[n] + (double)c->cfg.bn_eps);
+            sc[n] = (float)inv;
+            sh[n] = (float)(((double)L.bias[n] - (double)L.mean[n]) * inv + (double)L.beta[n]);
+        }
+        if ((rc = upload(c, &L.w, wt))) return rc;
+        if ((rc = upload(c, &L.scale, sc))) return rc;
+        if ((rc = upload(c, &L.shift, sh))) return rc;
+        std::vector<float>().swap(L.kernel);
+    }
+    // ---- regressor: Dense kernels [in,out] -> [out_pad][in_pad]; W1 split into features / theta parts
+    if (c->have_regressor) {
+        const std::vector<float>& k1 = c->dense[0].kernel;  // [2133][1024]
+        std::vector<float> w1f((size_t)1024 * 2048), w1t((size_t)1024 * THETA_LD, 0.f);
+        for (int n = 0; n < 1024; ++n) {
+            for (int k = 0; k < 2048; ++k) w1f[(size_t)n * 2048 + k] = k1[(size_t)k * 1024 + n];
+            for (int k = 0; k < HPE_THETA_DIM; ++k) w1t[(size_t)n * THETA_LD + k] = k1[(size_t)(2048 + k) * 1024 + n];
+        }
+        const std::vector<float>& k2 = c->dense[1].kernel;
+        std::vector<float> w2((size_t)1024 * 1024);
+        for (int n = 0; n < 1024; ++n)
+            for (int k = 0; k < 1024; ++k) w2[(size_t)n * 1024 + k] = k2[(size_t)k * 1024 + n];
+        const std::vector<float>& k3 = c->dense[2].kernel;  // [1024][85]
+        std::vector<float> w3((size_t)128 * 1024, 0.f);
+        for (int n = 0; n < HPE_THETA_DIM; ++n)
+            for (int k = 0; k < 1024; ++k) w3[(size_t)n * 1024 + k] = k3[(size_t)k * HPE_THETA_DIM + n];
+        if ((rc = upload(c, &c->w1f, w1f))) return rc;
+        if ((rc = upload(c, &c->w1t, w1t))) return rc;
+        if ((rc = upload(c, &c->w2, w2))) return rc;
+        if ((rc = upload(c, &c->w3, w3))) return rc;
+        if ((rc = upload(c, &c->b1, c->dense[0].bias))) return rc;
+        if ((rc = upload(c, &c->b2, c->dense[1].bias))) return rc;
+        std::vector<float> b3(128, 0.f);
+        for (int n = 0; n < HPE_THETA_DIM; ++n) b3[n] = c->dense[2].bias[n];
+        if ((rc = upload(c, &c->b3, b3))) return rc;
+        if ((rc = upload(c, &c->ones, std::vector<float>(1024, 1.f)))) return rc;
+        if ((rc = upload(c, &c->zeros, std::vector<float>(1024, 0.f)))) return rc;
+        if ((rc = upload(c, &c->mean_dev, std::vector<float>(c->h_mean, c->h_mean + HPE_THETA_DIM)))) return rc;
+    }
+    // ---- SMPL constants in kernel layouts
+    if (c->have_smpl) {
+        const int V = HPE_NUM_VERTS, V3 = V * 3;
+        // basis source [11][V*3]: row 0 v_template, rows 1..10 shapedirs^T  (shapedirs [V,3,10] -> [10][V*3])
+        std::vector<float> src((size_t)11 * V3);
+        memcpy(src.data(), c->h_vt.data(), sizeof(float) * V3);
+        for (int i = 0; i < V3; ++i)
+            for (int k = 0; k < 10; ++k) src[(size_t)(1 + k) * V3 + i] = c->h_sd[(size_t)i * 10 + k];
+        if ((rc = upload(c, &c->smpl_basis_src, src))) return rc;
+        c->smpl.v_template = c->smpl_basis_src;
+        c->smpl.shapedirs = c->smpl_basis_src + V3;
+        // posedirs [V,3,207] -> [207][V*3]
+        std::vector<float> pd((size_t)207 * V3);
+        for (int i = 0; i < V3; ++i)
+            for (int k = 0; k < 207; ++k) pd[(size_t)k * V3 + i] = c->h_pd[(size_t)i * 207 + k];
+        float* p = nullptr;
+        if ((rc = upload(c, &p, pd))) return rc;
+        c->smpl.posedirs = p;
+        if ((rc = upload(c, &p, c->h_w))) return rc;
+        c->smpl.weights = p;
+        // regressors [K,V] -> [V][24] zero padded
+        std::vector<float> jr((size_t)V * SMPL_KP_PITCH, 0.f), kr((size_t)V * SMPL_KP_PITCH, 0.f);
+        for (int j = 0; j < 24; ++j)
+            for (int v = 0; v < V; ++v) jr[(size_t)v * SMPL_KP_PITCH + j] = c->h_jreg[(size_t)j * V + v];
+        for (int j = 0; j < c->num_kp; ++j)
+            for (int v = 0; v < V; ++v) kr[(size_t)v * SMPL_KP_PITCH + j] = c->h_kreg[(size_t)j * V + v];
+        if ((rc = upload(c, &p, jr))) return rc;
+        c->smpl.j_reg = p;
+        if ((rc = upload(c, &p, kr))) return rc;
+        c->smpl.kp_reg = p;
+        int depth[24], maxd = 0;
+        for (int j = 0; j < 24; ++j) {
+            depth[j] = c->h_par[j] < 0 ? 0 : depth[c->h_par[j]] + 1;
+            if (depth[j] > maxd) maxd = depth[j];
+        }
+        void* ip = nullptr;
+        HIP_TRY(hipMalloc(&ip, sizeof(int) * 48));
+        c->allocs.push_back(ip);
+        HIP_TRY(hipMemcpy(ip, c->h_par.data(), sizeof(int) * 24, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(static_cast<int*>(ip) + 24, depth, sizeof(int) * 24, hipMemcpyHostToDevice));
+        c->smpl.parents = static_cast<int*>(ip);
+        c->smpl.depth = static_cast<int*>(ip) + 24;
+        c->smpl.max_depth = maxd;
+        c->smpl.num_kp = c->num_kp;
+        // 24-joint basis through the 6890 -> 24 joint-regressor kernel
+        float* jb = nullptr;
+        if ((rc = dev_alloc(c, &jb, 11 * 24 * 3, true))) return rc;
+        HIP_TRY(hpe_launch_joint_regress(c->smpl_basis_src, c->smpl.j_reg, 11, 24, jb, nullptr, nullptr, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        c->smpl.j_basis = jb;
+    }
+    // ---- workspace for max_batch images
+    {
+        const size_t B = (size_t)c->cfg.max_batch;
+        const size_t Bpad = (size_t)round_up(c->cfg.max_batch, SMPL_IMG_TILE);
+        if (c->have_encoder) {
+            if ((rc = dev_alloc(c, &c->padded, B * STEM_HP * STEM_WP * 4 + 64, true))) return rc;
+            if ((rc = dev_alloc(c, &c->X0, B * 802816, false))) return rc;
+            if ((rc = dev_alloc(c, &c->X1, B * 802816, false))) return rc;
+            if ((rc = dev_alloc(c, &c->SC, B * 802816, false))) return rc;
+            if ((rc = dev_alloc(c, &c->T1, B * 200704, false))) return rc;
+            if ((rc = dev_alloc(c, &c->T2, B * 200704, false))) return rc;
+            if ((rc = dev_alloc(c, &c->feat, B * HPE_FEATURE_DIM, true))) return rc;
+        }
+        if (c->have_regressor) {
+            if ((rc = dev_alloc(c, &c->P1, B * 1024, true))) return rc;
+            if ((rc = dev_alloc(c, &c->H1, B * 1024, true))) return rc;
+            if ((rc = dev_alloc(c, &c->H2, B * 1024, true))) return rc;
+            if ((rc = dev_alloc(c, &c->thA, B * THETA_LD, true))) return rc;
+            if ((rc = dev_alloc(c, &c->thB, B * THETA_LD, true))) return rc;
+        }
+        if (c->have_smpl) {
+            if ((rc = dev_alloc(c, &c->work.pfT, 207 * Bpad, true))) return rc;
+            if ((rc = dev_alloc(c, &c->work.betaT, 10 * Bpad, true))) return rc;
+            if ((rc = dev_alloc(c, &c->work.A, Bpad * 288, true))) return rc;
+            if ((rc = dev_alloc(c, &c->work.cams, Bpad * 4, true))) return rc;
+            if ((rc = dev_alloc(c, &c->work.verts_tmp, B * HPE_NUM_VERTS * 3, false))) return rc;
+        }
+        c->work.Bpad = (int)Bpad;
+    }
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->cev0) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->cev1) HIP_TRY(hipEventCreate(&e));
+    c->ev_ok = true;
+    HIP_TRY(hipDeviceSynchronize());
+    c->finalized = true;
+    return HPE_OK;
+}
+
+int hpe_encoder(hpe_ctx* c, const float* images, int B, float* features, void* stream) {
+    int rc = check_ready(c, B, NEED_ENC);
+    if (rc) return rc;
+    if (!images || !features) return fail(HPE_ERR_INVALID, "null pointer");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], st));
+    HIP_TRY(encoder_impl(c, images, B, features, HPE_FEATURE_DIM, st));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        HIP_TRY(hipEventRecord(c->ev[4], st));
+        c->timed_valid = true;
+        c->conv_timed_valid = c->timing >= 2;
+    }
+    return HPE_OK;
+}
+
+int hpe_regress_stage(hpe_ctx* c, const float* features, const float* theta_prev, int B, float* theta_out, void* stream) {
+    int rc = check_ready(c, B, NEED_REG);
+    if (rc) return rc;
+    if (!features || !theta_out) return fail(HPE_ERR_INVALID, "null pointer");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(features_proj(c, features, B, st));
+    if (theta_prev)
+        HIP_TRY(hpe_launch_copy_theta(theta_prev, HPE_THETA_DIM, c->thA, THETA_LD, B, HPE_THETA_DIM, st));
+    else
+        HIP_TRY(hpe_launch_tile_theta(c->mean_dev, c->thA, B, THETA_LD, st));
+    HIP_TRY(regress_impl(c, c->thA, c->thB, B, st));
+    HIP_TRY(hpe_launch_copy_theta(c->thB, THETA_LD, theta_out, HPE_THETA_DIM, B, HPE_THETA_DIM, st));
+    return HPE_OK;
+}
+
+int hpe_smpl(hpe_ctx* c, const float* theta, int B, const HpeOutputs* outs, void* stream) {
+    int rc = check_ready(c, B, NEED_SMPL);
+    if (rc) return rc;
+    if (!theta || !outs) return fail(HPE_ERR_INVALID, "null pointer");
+    DeviceGuard g(c->cfg.device);
+    HIP_TRY(hpe_launch_smpl(c->smpl, c->work, theta, HPE_THETA_DIM, B, outs, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_forward(hpe_ctx* c, const float* images, int B, const HpeOutputs* stage_outs, int n_outs, void* stream) {
+    int rc = check_ready(c, B, NEED_ENC | NEED_REG | NEED_SMPL);
+    if (rc) return rc;
+    if (!images || !stage_outs) return fail(HPE_ERR_INVALID, "null pointer");
+    if (n_outs < 1 || n_outs > c->cfg.num_stage) return fail(HPE_ERR_INVALID, "n_outs must be in [1, num_stage]");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool tm = c->timing != 0;
+    if (tm) HIP_TRY(hipEventRecord(c->ev[0], st));
+    HIP_TRY(encoder_impl(c, images, B, c->feat, HPE_FEATURE_DIM, st));
+    if (tm) HIP_TRY(hipEventRecord(c->ev[1], st));
+    HIP_TRY(features_proj(c, c->feat, B, st));
+    HIP_TRY(hpe_launch_tile_theta(c->mean_dev, c->thA, B, THETA_LD, st));
+    float* prev = c->thA;
+    float* next = c->thB;
+    const int first_out = c->cfg.num_stage - n_outs;
+    for (int s = 0; s < c->cfg.num_stage; ++s) {
+        HIP_TRY(regress_impl(c, prev, next, B, st));
+        if (s >= first_out) HIP_TRY(hpe_launch_smpl(c->smpl, c->work, next, THETA_LD, B, &stage_outs[s - first_out], st));
+        float* t = prev;
+        prev = next;
+        next = t;
+    }
+    if (tm) {
+        HIP_TRY(hipEventRecord(c->ev[4], st));
+        c->timed_valid = true;
+        c->conv_timed_valid = c->timing >= 2;
+    }
+    return HPE_OK;
+}
+
+int hpe_orth_proj(const float* X, const float* cam, int B, int P, float* out, void* stream) {
+    if (!X || !cam || !out || B < 1 || P < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    HIP_TRY(hpe_launch_orth_proj(X, cam, B, P, 0.f, 0.f, 0, out, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_reproject_vertices(const float* verts, const float* cam, int B, int P, float im_w, float im_h, float* out, void* stream) {
+    if (!verts || !cam || !out || B < 1 || P < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    HIP_TRY(hpe_launch_orth_proj(verts, cam, B, P, im_w, im_h, 1, out, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_kp_loss(const float* kp_gt, const float* kp_pred, int B, int K, float* out, void* stream) {
+    if (!kp_gt || !kp_pred || !out || B < 1 || K < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    HIP_TRY(hpe_launch_kp_loss(kp_gt, kp_pred, B * K, out, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_mesh_loss(hpe_ctx* c, const float* seg, const float* verts2d, int B, int H, int W, int P, float* out, void* stream) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    if (!seg || !verts2d || !out || B < 1 || H < 1 || W < 1 || P < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    DeviceGuard g(c->cfg.device);
+    const size_t need = hpe_mesh_loss_ws_floats(B, H, W, P);
+    if (need > c->loss_ws_floats) {  // first use (or a larger problem): grow the workspace -- synchronises once
+        HIP_TRY(hipDeviceSynchronize());
+        float* p = nullptr;
+        int rc = dev_alloc(c, &p, need, true);
+        if (rc) return rc;
+        c->loss_ws = p;
+        c->loss_ws_floats = need;
+    }
+    HIP_TRY(hpe_launch_mesh_loss(seg, verts2d, B, H, W, P, c->loss_ws, out, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* residual, int relu, float* y, void* stream) {
+    int rc = check_ready(c, B, NEED_ENC);
+    if (rc) return rc;
+    if (idx < 0 || idx >= HPE_NUM_CONV || !x || !y) return fail(HPE_ERR_INVALID, "bad argument");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* in = x;
+    if (idx == 0) {
+        HIP_TRY(hpe_launch_pad_input(x, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
+        in = c->padded;
+    }
+    HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st));
+    return HPE_OK;
+}
+
+int hpe_debug_maxpool(const float* x, int B, int H, int C, float* y, void* stream) {
+    if (!x || !y || B < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    HIP_TRY(hpe_launch_maxpool(x, y, B, H, C, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_debug_avgpool(const float* x, int B, int HW, int C, float* y, void* stream) {
+    if (!x || !y || B < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    HIP_TRY(hpe_launch_avgpool(x, y, B, HW, C, C, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_debug_joint_regress(hpe_ctx* c, const float* X, int n, int use_kp, float* out, void* stream) {
+    if (!c || !c->finalized || !c->have_smpl) return fail(HPE_ERR_STATE, "SMPL not finalized");
+    if (!X || !out || n < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    DeviceGuard g(c->cfg.device);
+    HIP_TRY(hpe_launch_joint_regress(X, use_kp ? c->smpl.kp_reg : c->smpl.j_reg, n, use_kp ? c->num_kp : 24, out, nullptr, nullptr,
+                                     static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_enable_timing(hpe_ctx* c, int enable) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    c->timing = enable;
+    c->timed_valid = false;
+    c->conv_timed_valid = false;
+    return HPE_OK;
+}
+
+int hpe_get_timings(hpe_ctx* c, float ms[5]) {
+    if (!c || !ms) return fail(HPE_ERR_INVALID, "null argument");
+    if (!c->timed_valid) return fail(HPE_ERR_STATE, "no timed call recorded (hpe_enable_timing first)");
+    DeviceGuard g(c->cfg.device);
+    HIP_TRY(hipEventSynchronize(c->ev[4]));
+    for (int i = 0; i < 5; ++i) ms[i] = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], c->ev[0], c->ev[4]));
+    if (c->conv_timed_valid) {
+        for (int i = 0; i < HPE_NUM_CONV; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->cev0[i], c->cev1[i]));
+            ms[1] += t;
+        }
+    }
+    ms[2] = ms[4] - ms[0];  // regressor + SMPL stages
+    return HPE_OK;
+}
+
+int hpe_get_conv_timings(hpe_ctx* c, float* ms) {
+    if (!c || !ms) return fail(HPE_ERR_INVALID, "null argument");
+    if (!c->conv_timed_valid) return fail(HPE_ERR_STATE, "no level-2 timed call recorded");
+    DeviceGuard g(c->cfg.device);
+    HIP_TRY(hipEventSynchronize(c->ev[4]));
+    for (int i = 0; i < HPE_NUM_CONV; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->cev0[i], c->cev1[i]));
+    return HPE_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,73 @@
+// hpe_internal.h -- shared declarations of libhpe_hip.so (not part of the C ABI; see include/hpe.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+enum GemmMode { GEMM_DENSE = 0, GEMM_STRIDED = 1, GEMM_CONV3 = 2, GEMM_STEM = 3 };
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3 };
+
+// Arguments of the implicit-GEMM kernel (conv_gemm.hip).  All offsets are in floats.
+struct GemmArgs {
+    const float* x;      // A source: activations (NHWC) or a dense [M, lda] matrix
+    const float* w;      // packed weights Wt[n][k], row pitch ldw, w_rows rows (zero padded)
+    const float* scale;  // [N]
+    const float* shift;  // [N]
+    const float* res;    // optional residual [M, ldres]
+    float* y;            // [M, ldy]
+    int M, N, K;         // K is a multiple of 32 (weights are zero padded along k)
+    int lda, ldw, ldy, ldres, w_rows;
+    int relu;
+    int Hi, Wi, Cin, Ho, Wo, stride, cin_slabs;
+    int n_mtiles, n_ntiles;  // filled by the launcher
+};
+
+hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st);
+
+// encoder_ops.hip
+hipError_t hpe_launch_pad_input(const float* img, float* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
+hipError_t hpe_launch_maxpool(const float* x, float* y, int B, int H, int C, hipStream_t st);
+hipError_t hpe_launch_avgpool(const float* x, float* y, int B, int HW, int C, int ldy, hipStream_t st);
+hipError_t hpe_launch_tile_theta(const float* mean85, float* theta, int B, int ld, hipStream_t st);
+hipError_t hpe_launch_copy_theta(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st);
+
+// smpl.hip
+struct SmplDev {
+    // constants (device)
+    const float* v_template;  // [V*3]
+    const float* shapedirs;   // [10][V*3]
+    const float* posedirs;    // [207][V*3]
+    const float* weights;     // [V][24]
+    const float* kp_reg;      // [V][KP_PITCH] (zero padded columns)
+    const float* j_reg;       // [V][KP_PITCH]
+    const float* j_basis;     // [11][24][3]  J of (v_template, shapedirs[0..9]) -- from the regress kernel
+    const int* parents;       // [24]
+    const int* depth;         // [24]
+    int num_kp;
+    int max_depth;
+};
+#define SMPL_V 6890
+#define SMPL_KP_PITCH 24
+#define SMPL_IMG_TILE 8
+
+struct SmplWork {
+    float* pfT;   // [207][Bpad]  pose feature, transposed
+    float* betaT; // [10][Bpad]
+    float* A;     // [Bpad][24][12]
+    float* cams;  // [Bpad][4] (s, tx, ty, 0)
+    float* verts_tmp; // [Bpad][V][3] used when the caller does not want verts but wants joints
+    int Bpad;
+};
+
+struct HpeOutputs;
+hipError_t hpe_launch_smpl(const SmplDev& d, const SmplWork& w, const float* theta, int ldtheta, int B, const HpeOutputs* o,
+                           hipStream_t st);
+hipError_t hpe_launch_joint_regress(const float* X, const float* reg, int n, int K, float* out, const float* cams,
+                                    float* kp2d, hipStream_t st);
+hipError_t hpe_launch_orth_proj(const float* X, const float* cam, int B, int P, float sx, float sy, int pixels, float* out,
+                                hipStream_t st);
+
+// losses.hip
+hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* out, hipStream_t st);
+size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P);
+hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
+                                hipStream_t st);

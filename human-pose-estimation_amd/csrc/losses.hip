@@ -1,0 +1,210 @@
+// losses.hip -- forward of the two reprojection losses the reference evaluates on the path's outputs
+// (BASELINE config 5): kp_reprojection_loss (src/ops.py:35-47) and mesh_reprojection_loss ->
+// bidirectional_dist -> find_nearest_neighbors (src/ops.py:60-137).
+//
+// The reference materialises a [P_i, 6890] fp32 distance matrix per image in a Python loop.  Here the
+// nearest-neighbour search is a tiled brute force: one point per lane with a running (min, argmin) in
+// registers, the other point set streamed through LDS (broadcast reads), no distance matrix in memory.
+// The squared distance is evaluated in the reference's expanded form ((-2 a.b) + |a|^2) + |b|^2 in fp32 and
+// ties keep the lowest index (tf.argmin), so the chosen neighbours follow the reference's choice.
+#include <hip/hip_runtime.h>
+
+#include "hpe_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] = sum vis*|gt-pred|, out[1] = #nonzero broadcast weights (2 per visible kp), out[2] = safe ratio
+__global__ __launch_bounds__(256) void kp_loss_kernel(const float* __restrict__ gt, const float* __restrict__ pred, int n,
+                                                      float* __restrict__ out) {
+    __shared__ float red[4];
+    float num = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gx = gt[i * 3], gy = gt[i * 3 + 1], vis = gt[i * 3 + 2];
+        const float px = pred[i * 2], py = pred[i * 2 + 1];
+        num += fabsf(px - gx) * vis + fabsf(py - gy) * vis;
+        cnt += (vis != 0.f) ? 2.f : 0.f;
+    }
+    const float tn = block_sum_256(num, red);
+    const float tc = block_sum_256(cnt, red);
+    if (threadIdx.x == 0) {
+        out[0] = tn;
+        out[1] = tc;
+        out[2] = tc > 0.f ? tn / tc : 0.f;
+    }
+}
+
+// ordered compaction of the silhouette pixels of image b: pts[b][i] = (x = col, y = row), row-major order
+// (tf.where order; src/trainer.py:291, src/ops.py:123-125).
+__global__ __launch_bounds__(256) void sil_compact_kernel(const float* __restrict__ seg, int HW, int W, float* __restrict__ pts,
+                                                          int* __restrict__ counts) {
+    __shared__ int scan[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int chunk = (HW + 255) / 256;
+    const int lo = t * chunk, hi = min(lo + chunk, HW);
+    const float* s = seg + (size_t)b * HW;
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += s[i] > 0.f ? 1 : 0;
+    scan[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = (t >= off) ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    int pos = scan[t] - c;
+    float* o = pts + (size_t)b * HW * 2;
+    for (int i = lo; i < hi; ++i) {
+        if (s[i] > 0.f) {
+            const int y = i / W;
+            o[2 * pos] = (float)(i - y * W);
+            o[2 * pos + 1] = (float)y;
+            ++pos;
+        }
+    }
+    if (t == 255) counts[b] = scan[255];
+}
+
+// direction A -> B: every silhouette point a finds its nearest mesh vertex, contributes |a - b*|_1.
+// grid (ceil(HW/256), B); B's P points live in dynamic LDS.
+__global__ __launch_bounds__(256) void nn_a2b_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
+                                                     const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
+                                                     int nblk) {
+    extern __shared__ __attribute__((aligned(16))) float sB[];  // [P][2]
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int cnt = counts[b];
+    const int base = blockIdx.x * 256;
+    if (base >= cnt) {
+        if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = 0.f;
+        return;
+    }
+    const float* Bp = v2d + (size_t)b * P * 2;
+    for (int i = threadIdx.x; i < 2 * P; i += 256) sB[i] = Bp[i];
+    __syncthreads();
+    const int idx = base + threadIdx.x;
+    float contrib = 0.f;
+    if (idx < cnt) {
+        const float ax = pts[((size_t)b * HW + idx) * 2], ay = pts[((size_t)b * HW + idx) * 2 + 1];
+        const float aa = ax * ax + ay * ay;
+        float best = 3.4e38f;
+        int bi = 0;
+        for (int p = 0; p < P; ++p) {
+            const float bx = sB[2 * p], by = sB[2 * p + 1];
+            const float d = (-2.0f * (ax * bx + ay * by) + aa) + (bx * bx + by * by);
+            if (d < best) {
+                best = d;
+                bi = p;
+            }
+        }
+        contrib = fabsf(ax - sB[2 * bi]) + fabsf(ay - sB[2 * bi + 1]);
+    }
+    const float s = block_sum_256(contrib, red);
+    if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = s;
+}
+
+// direction B -> A: every mesh vertex finds its nearest silhouette point, contributes ||b - a*||_2.
+// grid (ceil(P/256), B); A streamed through LDS in tiles of 2048 points.
+__global__ __launch_bounds__(256) void nn_b2a_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
+                                                     const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
+                                                     int nblk, int blk_off) {
+    __shared__ __attribute__((aligned(16))) float sA[2048 * 2];
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int cnt = counts[b];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < P;
+    const float bx = live ? v2d[((size_t)b * P + p) * 2] : 0.f;
+    const float by = live ? v2d[((size_t)b * P + p) * 2 + 1] : 0.f;
+    const float bb = bx * bx + by * by;
+    float best = 3.4e38f, cx = 0.f, cy = 0.f;
+    const float* Ap = pts + (size_t)b * HW * 2;
+    for (int t0 = 0; t0 < cnt; t0 += 2048) {
+        const int n = min(2048, cnt - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * n; i += 256) sA[i] = Ap[2 * t0 + i];
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            const float ax = sA[2 * i], ay = sA[2 * i + 1];
+            const float d = (-2.0f * (ax * bx + ay * by) + (ax * ax + ay * ay)) + bb;
+            if (d < best) {
+                best = d;
+                cx = ax;
+                cy = ay;
+            }
+        }
+    }
+    float contrib = 0.f;
+    if (live && cnt > 0) {
+        const float dx = bx - cx, dy = by - cy;
+        contrib = sqrtf(dx * dx + dy * dy);
+    }
+    const float s = block_sum_256(contrib, red);
+    if (threadIdx.x == 0) partial[(size_t)b * nblk + blk_off + blockIdx.x] = s;
+}
+
+// out[0] = sum_b ( sum of image b's partials ) / (3 + P), images added in index order (src/ops.py:129-136)
+__global__ __launch_bounds__(256) void mesh_loss_finish_kernel(const float* __restrict__ partial, int B, int nblk, int P,
+                                                               float* __restrict__ out) {
+    __shared__ float red[4];
+    float total = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += 256) v += partial[(size_t)b * nblk + i];
+        const float s = block_sum_256(v, red);
+        total += s / (float)(3 + P);
+    }
+    if (threadIdx.x == 0) out[0] = total;
+}
+
+}  // namespace
+
+hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(kp_loss_kernel, dim3(1), dim3(256), 0, st, gt, pred, n, out);
+    return hipGetLastError();
+}
+
+size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P) {
+    const int HW = H * W;
+    const int nblk = (HW + 255) / 256 + (P + 255) / 256;
+    return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64;
+}
+
+hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
+                                hipStream_t st) {
+    const int HW = H * W;
+    const int nA = (HW + 255) / 256, nB = (P + 255) / 256;
+    const int nblk = nA + nB;
+    if ((size_t)P * 2 * sizeof(float) > 150 * 1024) return hipErrorInvalidValue;  // B set must fit LDS
+    float* pts = ws;
+    float* partial = pts + (size_t)B * HW * 2;
+    int* counts = reinterpret_cast<int*>(partial + (size_t)B * nblk);
+    hipLaunchKernelGGL(sil_compact_kernel, dim3(B), dim3(256), 0, st, seg, HW, W, pts, counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t shm = (size_t)P * 2 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && shm > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(nn_a2b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), shm, st, pts, counts, v2d, HW, P, partial, nblk);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nn_b2a_kernel, dim3(nB, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk, nA);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, B, nblk, P, out);
+    return hipGetLastError();
+}

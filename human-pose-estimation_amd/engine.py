@@ -1,0 +1,285 @@
+"""HpeEngine: thin owner of one ``hpe_ctx`` (include/hpe.h) -- asset ingestion from Keras-layout dicts and
+torch-tensor plumbing around the C-ABI calls.  PyTorch is used for device memory, streams and (in
+``distributed.py``) the RCCL process group only; every numerical stage runs in libhpe_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .resnet_spec import CONV_SPECS
+
+NUM_VERTS = _lib.NUM_VERTS
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _require_cuda_tensor(t, name, shape_tail=None):
+    torch = _torch()
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor on the GPU" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError("%s must have shape [B,%s], got %s" % (name, ",".join(map(str, shape_tail)), tuple(t.shape)))
+    return t.contiguous()
+
+
+class HpeEngine(object):
+    def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3):
+        self.lib = _lib.load()
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.HpeError("no GPU visible: the HIP path is the only path (no CPU fallback)")
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        self.num_stage = int(num_stage)
+        self.num_kp = 19
+        cfg = _lib.HpeConfig(self.device, self.max_batch, self.num_stage, float(bn_eps), 0)
+        h = C.c_void_p()
+        _lib.check(self.lib.hpe_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._finalized = False
+        self.tdev = torch.device("cuda", self.device)
+
+    # ------------------------------------------------------------------ ingestion
+    def load_smpl(self, model, joint_type="cocoplus"):
+        """model: dict with the reference pickle's keys (src/tf_smpl/batch_smpl.py:31-81); scipy-sparse
+        regressors and chumpy-like objects (``.r``) are densified here exactly as the reference does."""
+
+        def dense(x):
+            if hasattr(x, "todense"):
+                x = np.asarray(x.todense())
+            elif hasattr(x, "r") and not isinstance(x, np.ndarray):
+                x = np.asarray(x.r)
+            return np.asarray(x)
+
+        if joint_type not in ("cocoplus", "lsp"):
+            raise ValueError('BAD!! Unknown joint type: %s, it must be either "cocoplus" or "lsp"' % joint_type)
+        kp = dense(model["cocoplus_regressor"])
+        if joint_type == "lsp":
+            kp = kp[:14]
+        parents = np.ascontiguousarray(np.asarray(model["kintree_table"])[0].astype(np.int64).astype(np.int32))
+        parents[parents < 0] = -1
+        parents[0] = -1  # uint32(-1) -> int32 (batch_smpl.py:65)
+        keep = [_lib.f32(dense(model[k])) for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights")]
+        keep.append(_lib.f32(kp))
+        if keep[0][0].shape != (NUM_VERTS, 3) or keep[1][0].shape != (NUM_VERTS, 3, 10) or keep[2][0].shape != (NUM_VERTS, 3, 207):
+            raise ValueError("SMPL arrays have unexpected shapes")
+        if keep[3][0].shape != (24, NUM_VERTS) or keep[4][0].shape != (NUM_VERTS, 24) or keep[5][0].shape[1] != NUM_VERTS:
+            raise ValueError("SMPL regressor/weight arrays have unexpected shapes")
+        m = _lib.HpeSmplModel(*[k[1] for k in keep], parents.ctypes.data_as(C.c_void_p), int(kp.shape[0]))
+        _lib.check(self.lib.hpe_load_smpl(self._h, C.byref(m)))
+        self.num_kp = int(kp.shape[0])
+
+    def load_encoder(self, params):
+        """params: {'<layer>/kernel' HWIO, '<layer>/bias', '<bn>/gamma|beta|moving_mean|moving_variance'}"""
+        for i, s in enumerate(CONV_SPECS):
+            arrs = [
+                _lib.f32(params[s.name + "/kernel"]),
+                _lib.f32(params[s.name + "/bias"]),
+                _lib.f32(params[s.bn_name + "/gamma"]),
+                _lib.f32(params[s.bn_name + "/beta"]),
+                _lib.f32(params[s.bn_name + "/moving_mean"]),
+                _lib.f32(params[s.bn_name + "/moving_variance"]),
+            ]
+            if arrs[0][0].shape != (s.kh, s.kw, s.cin, s.cout):
+                raise ValueError("%s/kernel must be HWIO %s, got %s" % (s.name, (s.kh, s.kw, s.cin, s.cout), arrs[0][0].shape))
+            _lib.check(self.lib.hpe_load_conv(self._h, i, *[a[1] for a in arrs]))
+
+    def load_regressor(self, params):
+        dims = [(2133, 1024), (1024, 1024), (1024, 85)]
+        for i, d in enumerate(dims):
+            k = _lib.f32(params["dense_%d/kernel" % i])
+            b = _lib.f32(params["dense_%d/bias" % i])
+            if k[0].shape != d:
+                raise ValueError("dense_%d/kernel must be %s" % (i, d))
+            _lib.check(self.lib.hpe_load_dense(self._h, i, k[1], b[1]))
+
+    def load_mean_theta(self, mean85):
+        m = _lib.f32(np.asarray(mean85).reshape(-1))
+        if m[0].shape != (85,):
+            raise ValueError("mean theta must have 85 entries")
+        _lib.check(self.lib.hpe_load_mean_theta(self._h, m[1]))
+
+    def finalize(self):
+        _lib.check(self.lib.hpe_finalize(self._h))
+        self._finalized = True
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.hpe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.tdev).cuda_stream)
+
+    def _new(self, *shape):
+        return _torch().empty(shape, dtype=_torch().float32, device=self.tdev)
+
+    def _alloc_outputs(self, B, want):
+        shapes = {
+            "verts": (B, NUM_VERTS, 3),
+            "joints": (B, self.num_kp, 3),
+            "cams": (B, 3),
+            "theta": (B, 85),
+            "J_transformed": (B, 24, 3),
+            "kp2d": (B, self.num_kp, 2),
+            "verts2d": (B, NUM_VERTS, 2),
+            "Rs": (B, 24, 3, 3),
+        }
+        tensors = {k: self._new(*shapes[k]) for k in want}
+        o = _lib.HpeOutputs(*[tensors[k].data_ptr() if k in tensors else None for k in _lib.OUTPUT_FIELDS])
+        return tensors, o
+
+    # ------------------------------------------------------------------ compute
+    DEFAULT_OUTPUTS = ("verts", "joints", "cams", "theta", "J_transformed", "kp2d")
+
+    def forward(self, images, all_stages=False, want=DEFAULT_OUTPUTS):
+        """images [B,224,224,3] cuda float32 -> list (one dict per returned stage) of output tensors."""
+        images = _require_cuda_tensor(images, "images", (224, 224, 3))
+        B = images.shape[0]
+        n_outs = self.num_stage if all_stages else 1
+        outs = []
+        arr = (_lib.HpeOutputs * n_outs)()
+        for i in range(n_outs):
+            t, o = self._alloc_outputs(B, want)
+            outs.append(t)
+            arr[i] = o
+        _lib.check(self.lib.hpe_forward(self._h, images.data_ptr(), B, arr, n_outs, self._stream()))
+        return outs
+
+    def make_forward_plan(self, B, all_stages=False, want=DEFAULT_OUTPUTS):
+        """Pre-allocate outputs once; returns (callable(images), outputs) -- the steady-state serving path."""
+        n_outs = self.num_stage if all_stages else 1
+        outs = []
+        arr = (_lib.HpeOutputs * n_outs)()
+        for i in range(n_outs):
+            t, o = self._alloc_outputs(B, want)
+            outs.append(t)
+            arr[i] = o
+        lib, h = self.lib, self._h
+
+        def run(images):
+            _lib.check(lib.hpe_forward(h, images.data_ptr(), B, arr, n_outs, self._stream()))
+            return outs
+
+        return run, outs
+
+    def encoder(self, images):
+        images = _require_cuda_tensor(images, "images", (224, 224, 3))
+        feat = self._new(images.shape[0], 2048)
+        _lib.check(self.lib.hpe_encoder(self._h, images.data_ptr(), images.shape[0], feat.data_ptr(), self._stream()))
+        return feat
+
+    def regress_stage(self, features, theta_prev=None):
+        features = _require_cuda_tensor(features, "features", (2048,))
+        B = features.shape[0]
+        tp = None
+        if theta_prev is not None:
+            theta_prev = _require_cuda_tensor(theta_prev, "theta_prev", (85,))
+            tp = theta_prev.data_ptr()
+        out = self._new(B, 85)
+        _lib.check(self.lib.hpe_regress_stage(self._h, features.data_ptr(), tp, B, out.data_ptr(), self._stream()))
+        return out
+
+    def smpl(self, theta, want=("verts", "joints", "J_transformed", "kp2d", "Rs")):
+        theta = _require_cuda_tensor(theta, "theta", (85,))
+        B = theta.shape[0]
+        t, o = self._alloc_outputs(B, want)
+        _lib.check(self.lib.hpe_smpl(self._h, theta.data_ptr(), B, C.byref(o), self._stream()))
+        return t
+
+    def mesh_loss(self, seg, verts2d):
+        torch = _torch()
+        seg = _require_cuda_tensor(seg, "seg")
+        verts2d = _require_cuda_tensor(verts2d, "verts2d")
+        B, H, W = seg.shape[0], seg.shape[1], seg.shape[2]
+        P = verts2d.shape[1]
+        out = torch.zeros(4, dtype=torch.float32, device=self.tdev)
+        _lib.check(self.lib.hpe_mesh_loss(self._h, seg.data_ptr(), verts2d.data_ptr(), B, H, W, P, out.data_ptr(), self._stream()))
+        return out[0]
+
+    def debug_conv(self, idx, x, residual=None, relu=True):
+        s = CONV_SPECS[idx]
+        x = _require_cuda_tensor(x, "x")
+        B = x.shape[0]
+        y = self._new(B, s.hout, s.hout, s.cout)
+        r = None
+        if residual is not None:
+            r = _require_cuda_tensor(residual, "residual").data_ptr()
+        _lib.check(self.lib.hpe_debug_conv(self._h, idx, x.data_ptr(), B, r, int(relu), y.data_ptr(), self._stream()))
+        return y
+
+    def joint_regress(self, X, use_kp_regressor=True):
+        X = _require_cuda_tensor(X, "X", (NUM_VERTS, 3))
+        K = self.num_kp if use_kp_regressor else 24
+        out = self._new(X.shape[0], K, 3)
+        _lib.check(self.lib.hpe_debug_joint_regress(self._h, X.data_ptr(), X.shape[0], int(use_kp_regressor), out.data_ptr(), self._stream()))
+        return out
+
+    def enable_timing(self, level=1):
+        _lib.check(self.lib.hpe_enable_timing(self._h, int(level)))
+
+    def timings(self):
+        ms = (C.c_float * 5)()
+        _lib.check(self.lib.hpe_get_timings(self._h, ms))
+        return dict(encoder_ms=ms[0], conv_ms=ms[1], regress_smpl_ms=ms[2], total_ms=ms[4])
+
+    def conv_timings(self):
+        ms = (C.c_float * _lib.NUM_CONV)()
+        _lib.check(self.lib.hpe_get_conv_timings(self._h, ms))
+        return list(ms)
+
+
+# ---------------------------------------------------------------------- context-free operators
+def _cur_stream(t):
+    return C.c_void_p(_torch().cuda.current_stream(t.device).cuda_stream)
+
+
+def orth_proj(X, camera):
+    X = _require_cuda_tensor(X, "X")
+    camera = _require_cuda_tensor(camera, "camera").reshape(-1, 3)
+    B, P = X.shape[0], X.shape[1]
+    out = _torch().empty((B, P, 2), dtype=_torch().float32, device=X.device)
+    with _torch().cuda.device(X.device):
+        _lib.check(_lib.load().hpe_orth_proj(X.data_ptr(), camera.data_ptr(), B, P, out.data_ptr(), _cur_stream(X)))
+    return out
+
+
+def reproject(verts, cam, im_w, im_h):
+    verts = _require_cuda_tensor(verts, "verts")
+    cam = _require_cuda_tensor(cam, "cam").reshape(-1, 3)
+    B, P = verts.shape[0], verts.shape[1]
+    out = _torch().empty((B, P, 2), dtype=_torch().float32, device=verts.device)
+    with _torch().cuda.device(verts.device):
+        _lib.check(
+            _lib.load().hpe_reproject_vertices(verts.data_ptr(), cam.data_ptr(), B, P, float(im_w), float(im_h), out.data_ptr(), _cur_stream(verts))
+        )
+    return out
+
+
+def kp_loss_parts(kp_gt, kp_pred):
+    """-> tensor [3]: (sum vis*|d|, 2*#visible, loss)"""
+    kp_gt = _require_cuda_tensor(kp_gt, "kp_gt")
+    kp_pred = _require_cuda_tensor(kp_pred, "kp_pred")
+    B, K = kp_gt.shape[0], kp_gt.shape[1]
+    out = _torch().zeros(4, dtype=_torch().float32, device=kp_gt.device)
+    with _torch().cuda.device(kp_gt.device):
+        _lib.check(_lib.load().hpe_kp_loss(kp_gt.data_ptr(), kp_pred.data_ptr(), B, K, out.data_ptr(), _cur_stream(kp_gt)))
+    return out[:3]

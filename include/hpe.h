@@ -1,0 +1,164 @@
+/*
+ * hpe.h -- C ABI of libhpe_hip.so: the MI355X (gfx950) implementation of the per-image forward hot
+ * path of maxpit/human-pose-estimation (ResNet-50 v1 encoder -> 3-stage iterative SMPL-parameter
+ * regressor -> SMPL linear blend skinning -> orthographic reprojection).
+ *
+ * The reference has NO plugin / operator / FFI interface: the Python class
+ * `Predictor` (reference: src/predictor.py:26-163) *is* the interface.  This header is therefore the
+ * boundary a maintainer's ctypes binding would call from `Predictor.__init__` / `Predictor.predict`;
+ * every entry point cites the reference code it replaces.  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, int return codes (HPE_OK == 0), no exceptions cross the ABI,
+ *     `hpe_last_error()` returns a thread-local message for the last failing call.
+ *   - "host" pointers are read during the call and not retained; "dev" pointers are HIP device
+ *     pointers owned by the caller (e.g. torch tensors' data_ptr()).  All tensors are dense float32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  No call synchronises the
+ *     device except hpe_create / hpe_load_* / hpe_finalize / hpe_destroy / hpe_get_timings.
+ *   - one ctx per device; a ctx is not re-entrant (the reference is not either: SMPL.J_transformed is
+ *     mutated per call, src/tf_smpl/batch_smpl.py:135).
+ *   - theta layout (kept from the reference, src/predictor.py:136-138):
+ *         [ s, tx, ty | 72 axis-angle (root first) | 10 betas ]  = 85 floats.
+ */
+#ifndef HPE_H_
+#define HPE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPE_OK 0
+#define HPE_ERR_INVALID 1   /* bad argument / shape */
+#define HPE_ERR_HIP 2       /* a HIP runtime call failed */
+#define HPE_ERR_STATE 3     /* call order violated (e.g. forward before finalize) */
+#define HPE_ERR_NO_DEVICE 4 /* no gfx950 device visible */
+
+#define HPE_NUM_CONV 53      /* ResNet-50 v1 conv layers, order of hpe_conv_layer_name() */
+#define HPE_NUM_DENSE 3      /* RegressionNetwork: 2133->1024->1024->85 */
+#define HPE_NUM_VERTS 6890
+#define HPE_NUM_JOINTS 24
+#define HPE_NUM_BETAS 10
+#define HPE_NUM_POSE_BASIS 207
+#define HPE_THETA_DIM 85
+#define HPE_FEATURE_DIM 2048
+#define HPE_MAX_KP 24
+#define HPE_IMG_SIZE 224
+
+typedef struct hpe_ctx hpe_ctx;
+
+typedef struct HpeConfig {
+    int device;     /* HIP device ordinal */
+    int max_batch;  /* workspace is sized for this many images per call (<= 1024) */
+    int num_stage;  /* IEF iterations; reference default 3 (src/config.py:39) */
+    float bn_eps;   /* BatchNorm epsilon: 1e-3 (keras_applications 1.0.8) or 1.001e-5 (tf.keras >= 2.2) */
+    int encoder_dtype; /* 0 = fp32 MFMA (default), 1 = bf16 MFMA with fp32 accumulate (config 4) */
+} HpeConfig;
+
+/* SMPL constants as the reference holds them after SMPL.__init__ (src/tf_smpl/batch_smpl.py:31-81),
+ * as dense host arrays in the pickle's own layouts. */
+typedef struct HpeSmplModel {
+    const float* v_template;   /* [6890,3] */
+    const float* shapedirs;    /* [6890,3,10] */
+    const float* posedirs;     /* [6890,3,207] */
+    const float* J_regressor;  /* [24,6890]  (the sparse matrix, densified) */
+    const float* weights;      /* [6890,24] */
+    const float* kp_regressor; /* [num_kp,6890]  cocoplus_regressor (or its first 14 rows for 'lsp') */
+    const int* parents;        /* [24] kintree_table[0] as int32, parents[0] == -1, parents[i] < i */
+    int num_kp;                /* 19 (cocoplus, the reference default) or 14 (lsp) */
+} HpeSmplModel;
+
+/* Device output pointers of one IEF stage.  Any pointer may be NULL (that output is not written). */
+typedef struct HpeOutputs {
+    float* verts;          /* [B,6890,3]    generated_verts   (src/predictor.py:155) */
+    float* joints;         /* [B,num_kp,3]  generated_joints  (src/predictor.py:154) */
+    float* cams;           /* [B,3]         generated_cams    (src/predictor.py:156) */
+    float* theta;          /* [B,85] */
+    float* J_transformed;  /* [B,24,3]      smpl.J_transformed (src/tf_smpl/batch_smpl.py:135) */
+    float* kp2d;           /* [B,num_kp,2]  batch_orth_proj_idrot(joints, cams) (src/trainer.py:274) */
+    float* verts2d;        /* [B,6890,2]    reproject_vertices(verts, cams, [224,224]) (src/trainer.py:285) */
+    float* Rs;             /* [B,24,3,3]    rotation matrices (third return of SMPL.__call__) */
+} HpeOutputs;
+
+const char* hpe_last_error(void);
+const char* hpe_version(void);
+
+/* Keras layer name of conv `idx` ("conv1", "res2a_branch2a", ... ) and of its BatchNorm. */
+const char* hpe_conv_layer_name(int idx);
+const char* hpe_bn_layer_name(int idx);
+/* geometry of conv `idx`: out[0..6] = KH, KW, Cin, Cout, stride, Hin, Hout */
+int hpe_conv_layer_geometry(int idx, int out[7]);
+
+/* -- lifetime: replaces Predictor.__init__ (src/predictor.py:27-86) minus renderer/optimizers/critic -- */
+int hpe_create(const HpeConfig* cfg, hpe_ctx** out);
+int hpe_destroy(hpe_ctx* ctx);
+
+/* SMPL(pkl_path) constants (src/predictor.py:55 -> src/tf_smpl/batch_smpl.py:26-86). */
+int hpe_load_smpl(hpe_ctx* ctx, const HpeSmplModel* host_model);
+/* One Keras Conv2D + its BatchNorm, Keras layouts: kernel HWIO [KH,KW,Cin,Cout], bias/gamma/beta/
+ * moving_mean/moving_variance [Cout] (EncoderNetwork weights, src/models.py:35-41; restored from the
+ * checkpoint's `feature_extractor`, src/predictor.py:79-86). */
+int hpe_load_conv(hpe_ctx* ctx, int idx, const float* kernel_hwio, const float* bias, const float* gamma,
+                  const float* beta, const float* moving_mean, const float* moving_variance);
+/* One Keras Dense of RegressionNetwork: kernel [in,out], bias [out] (src/models.py:60-74). */
+int hpe_load_dense(hpe_ctx* ctx, int idx, const float* kernel_in_out, const float* bias);
+/* mean theta [85] (load_mean_param, src/predictor.py:88-110 / checkpoint's `inital_theta`). */
+int hpe_load_mean_theta(hpe_ctx* ctx, const float* mean85);
+/* Pack weights for the kernels, fold BN into per-channel scale/shift, precompute the joint-regressor
+ * basis on the device.  Must be called after all hpe_load_* and before any compute call. */
+int hpe_finalize(hpe_ctx* ctx);
+
+/* -- the hot path: replaces the body of Predictor.predict (src/predictor.py:114-158) --------------
+ * images_dev [B,224,224,3] NHWC float32 in [-1,1].  stage_outs[i] (i < n_outs) receives IEF stage
+ * (num_stage - n_outs + i): n_outs == 1 gives the reference's `predict` result (last stage only, SMPL
+ * of the earlier stages -- dead work in the reference -- is skipped); n_outs == num_stage gives what
+ * Trainer.val_step consumes (src/trainer.py:242-298). */
+int hpe_forward(hpe_ctx* ctx, const float* images_dev, int B, const HpeOutputs* stage_outs, int n_outs, void* stream);
+
+/* -- operators of the path, individually (same kernels as hpe_forward) -------------------------- */
+/* image_feature_extractor.predict(images) (src/predictor.py:125): -> features_dev [B,2048] */
+int hpe_encoder(hpe_ctx* ctx, const float* images_dev, int B, float* features_dev, void* stream);
+/* one IEF step: theta_out = theta_prev + generator3d([features | theta_prev]) (src/predictor.py:129-133).
+ * theta_prev_dev == NULL means tile(mean_var) (src/predictor.py:126). */
+int hpe_regress_stage(hpe_ctx* ctx, const float* features_dev, const float* theta_prev_dev, int B, float* theta_out_dev,
+                      void* stream);
+/* self.smpl(shapes, poses, get_skin=True) + proj_fn on theta rows [B,85] (src/predictor.py:136-141). */
+int hpe_smpl(hpe_ctx* ctx, const float* theta_dev, int B, const HpeOutputs* outs, void* stream);
+/* batch_orth_proj_idrot (src/tf_smpl/projection.py:23-33): X [B,P,3], cam [B,3] -> out [B,P,2] */
+int hpe_orth_proj(const float* X_dev, const float* cam_dev, int B, int P, float* out_dev, void* stream);
+/* reproject_vertices (src/tf_smpl/projection.py:45-56): out = (proj + 1) * 0.5 * im_size */
+int hpe_reproject_vertices(const float* verts_dev, const float* cam_dev, int B, int P, float im_w, float im_h, float* out_dev,
+                           void* stream);
+/* kp_reprojection_loss (src/ops.py:35-47): kp_gt [B,K,3], kp_pred [B,K,2] -> out_dev[0] = sum(vis*|d|),
+ * out_dev[1] = 2*#visible (the SUM_BY_NONZERO_WEIGHTS denominator), out_dev[2] = loss (0 if nothing visible).
+ * Numerator and count are returned separately so that ranks can all-reduce them before dividing. */
+int hpe_kp_loss(const float* kp_gt_dev, const float* kp_pred_dev, int B, int K, float* out_dev, void* stream);
+/* mesh_reprojection_loss (src/ops.py:117-137) forward: seg_dev [B,H,W] (>0 = silhouette), verts2d_dev
+ * [B,P,2] pixels -> out_dev[0] = sum_i bidirectional_dist_i / (3 + P).  workspace from the ctx. */
+int hpe_mesh_loss(hpe_ctx* ctx, const float* seg_dev, const float* verts2d_dev, int B, int H, int W, int P, float* out_dev,
+                  void* stream);
+
+/* -- test / measurement hooks -------------------------------------------------------------------- */
+/* Run loaded conv layer `idx` (+BN, optional residual, optional ReLU) on x_dev [B,Hin,Hin,Cin] ->
+ * y_dev [B,Hout,Hout,Cout]; for idx 0 the input is the raw [B,224,224,3] image and y is the
+ * post-ReLU conv1 output [B,112,112,64]. */
+int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float* residual_dev, int relu, float* y_dev,
+                   void* stream);
+/* ZeroPad(1)+MaxPool3x3/2: x [B,H,H,C] -> y [B,H/2,H/2,C];  global average pool x [B,HW,C] -> y [B,C] */
+int hpe_debug_maxpool(const float* x_dev, int B, int H, int C, float* y_dev, void* stream);
+int hpe_debug_avgpool(const float* x_dev, int B, int HW, int C, float* y_dev, void* stream);
+/* generic regressor: out[n,k,c] = sum_v X[n,v,c] * reg[v,k]  (the 6890 -> K joint regressor kernel) */
+int hpe_debug_joint_regress(hpe_ctx* ctx, const float* X_dev, int n, int use_kp_regressor, float* out_dev, void* stream);
+/* Timing: level 1 brackets the phases of hpe_forward / hpe_encoder with HIP events recorded on `stream`;
+ * level 2 additionally brackets every conv launch (adds ~100 event records per call).
+ * hpe_get_timings synchronises on the last event and returns milliseconds of the LAST call:
+ *   ms[0] encoder (pad + 53 convs + pools), ms[1] sum over the 53 conv launches (level 2, else 0),
+ *   ms[2] regressor + SMPL stages, ms[3] reserved (0), ms[4] whole call. */
+int hpe_enable_timing(hpe_ctx* ctx, int level);
+int hpe_get_timings(hpe_ctx* ctx, float ms[5]);
+/* per-conv-layer milliseconds of the last level-2 timed call: ms53[HPE_NUM_CONV] */
+int hpe_get_conv_timings(hpe_ctx* ctx, float* ms53);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPE_H_ */

@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads, and exports exactly the
+symbols include/hpe.h declares (no compute calls -- there is no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+import hpe_amd
+from hpe_amd import _lib, build as hbuild, resnet_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    hbuild.build()
+    return _lib.load()
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "hpe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hpe_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree(lib):
+    hdr = _header_functions()
+    assert hdr == _lib.declared_symbols(), (set(hdr) ^ set(_lib.declared_symbols()))
+    for name in hdr:
+        assert hasattr(lib, name), "library does not export %s" % name
+
+
+def test_layer_table_matches_host_spec(lib):
+    import ctypes as C
+
+    geo = (C.c_int * 7)()
+    for i, s in enumerate(resnet_spec.CONV_SPECS):
+        assert lib.hpe_conv_layer_name(i).decode() == s.name
+        assert lib.hpe_bn_layer_name(i).decode() == s.bn_name
+        assert lib.hpe_conv_layer_geometry(i, geo) == 0
+        assert tuple(geo) == (s.kh, s.kw, s.cin, s.cout, s.stride, s.hin, s.hout)
+    assert lib.hpe_conv_layer_name(53) is None
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hpe_amd.HpeError):
+        hpe_amd.HpeEngine()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "human-pose-estimation_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C-ABI library and is
+compared with the CPU oracle on identical seeded inputs.
+
+Tolerance (BASELINE north_star: "within 1e-4 relative fp32"): rel(a, b) = max|a-b| / max|b| <= 1e-4 for
+verts / joints / kp2d / theta; single kernels are held to tighter bounds written at each assert.
+"""
+import numpy as np
+import pytest
+
+import hpe_amd
+from hpe_amd import resnet_spec, synthetic
+from oracle import hmr_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def gpu(x):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def assets():
+    a = dict(
+        smpl=synthetic.make_smpl_model(),
+        enc=synthetic.make_encoder_params(),
+        reg=synthetic.make_regressor_params(),
+        mean=synthetic.make_mean_params(),
+    )
+    a["mean_var"] = O.load_mean_param(a["mean"])
+    a["osmpl"] = O.SMPL(a["smpl"])
+    return a
+
+
+@pytest.fixture(scope="module")
+def engine(assets):
+    e = hpe_amd.HpeEngine(device=0, max_batch=16)
+    e.load_smpl(assets["smpl"])
+    e.load_encoder(assets["enc"])
+    e.load_regressor(assets["reg"])
+    e.load_mean_theta(assets["mean_var"])
+    e.finalize()
+    yield e
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------- SMPL
+@pytest.mark.parametrize("B", [1, 5, 16])
+def test_smpl_matches_oracle(engine, assets, B):
+    th = synthetic.make_thetas(B, seed=11 + B)
+    out = engine.smpl(gpu(th), want=("verts", "joints", "J_transformed", "kp2d", "Rs", "verts2d", "cams", "theta"))
+    v, j, Rs = assets["osmpl"](th[:, 75:], th[:, 3:75], get_skin=True)
+    assert rel(cpu(out["Rs"]), Rs) < 2e-6
+    assert rel(cpu(out["J_transformed"]), assets["osmpl"].J_transformed) < 5e-6
+    assert rel(cpu(out["verts"]), v) < 1e-5
+    assert rel(cpu(out["joints"]), j) < 1e-5
+    assert rel(cpu(out["kp2d"]), O.batch_orth_proj_idrot(j, th[:, :3])) < 1e-5
+    assert rel(cpu(out["verts2d"]), O.reproject_vertices(v, th[:, :3], np.array([224.0, 224.0], np.float32))) < 1e-5
+    np.testing.assert_array_equal(cpu(out["theta"]), th)
+    np.testing.assert_array_equal(cpu(out["cams"]), th[:, :3])
+
+
+def test_smpl_rest_pose_kat(engine, assets):
+    th = np.zeros((2, 85), np.float32)
+    out = engine.smpl(gpu(th), want=("verts", "J_transformed"))
+    assert np.abs(cpu(out["verts"])[0] - assets["smpl"]["v_template"]).max() < 2e-6
+    J0 = assets["smpl"]["J_regressor"].astype(np.float64) @ assets["smpl"]["v_template"].astype(np.float64)
+    assert np.abs(cpu(out["J_transformed"])[1] - J0).max() < 2e-6
+
+
+def test_smpl_class_surface(assets):
+    sm = hpe_amd.SMPL(assets["smpl"], max_batch=8)
+    th = synthetic.make_thetas(3, seed=3)
+    joints = sm(th[:, 75:], th[:, 3:75])
+    verts, joints2, Rs = sm(gpu(th[:, 75:]), gpu(th[:, 3:75]), get_skin=True)
+    v, j, _ = assets["osmpl"](th[:, 75:], th[:, 3:75], get_skin=True)
+    assert tuple(joints.shape) == (3, 19, 3) and tuple(verts.shape) == (3, 6890, 3) and tuple(Rs.shape) == (3, 24, 3, 3)
+    assert rel(cpu(joints), j) < 1e-5 and rel(cpu(joints2), j) < 1e-5 and rel(cpu(verts), v) < 1e-5
+    assert rel(cpu(sm.J_transformed), assets["osmpl"].J_transformed) < 5e-6
+
+
+def test_joint_regressor_kernel(engine, assets):
+    g = np.random.Generator(np.random.Philox(5))
+    X = g.normal(0, 1, (3, 6890, 3)).astype(np.float32)
+    out24 = cpu(engine.joint_regress(gpu(X), use_kp_regressor=False))
+    out19 = cpu(engine.joint_regress(gpu(X), use_kp_regressor=True))
+    ref24 = np.einsum("nvc,jv->njc", X.astype(np.float64), assets["smpl"]["J_regressor"].astype(np.float64))
+    ref19 = np.einsum("nvc,jv->njc", X.astype(np.float64), assets["smpl"]["cocoplus_regressor"].astype(np.float64))
+    assert rel(out24, ref24) < 2e-6 and rel(out19, ref19) < 2e-6
+
+
+def test_projection_ops():
+    g = np.random.Generator(np.random.Philox(6))
+    X = g.normal(0, 1, (4, 37, 3)).astype(np.float32)
+    cam = np.abs(g.normal(1, 0.2, (4, 3))).astype(np.float32)
+    assert rel(cpu(hpe_amd.batch_orth_proj_idrot(gpu(X), gpu(cam))), O.batch_orth_proj_idrot(X, cam)) < 1e-6
+    ref = O.reproject_vertices(X, cam, np.array([224.0, 224.0], np.float32))
+    assert rel(cpu(hpe_amd.reproject_vertices(gpu(X), gpu(cam), [224.0, 224.0])), ref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- encoder
+def _bn_fold(p, s, eps=1e-3):
+    g, b = p[s.bn_name + "/gamma"].astype(np.float64), p[s.bn_name + "/beta"].astype(np.float64)
+    m, v = p[s.bn_name + "/moving_mean"].astype(np.float64), p[s.bn_name + "/moving_variance"].astype(np.float64)
+    return g / np.sqrt(v + eps), b - m * g / np.sqrt(v + eps)
+
+
+CONV_CASES = ["conv1", "res2a_branch2a", "res2a_branch2b", "res2a_branch2c", "res2a_branch1", "res3a_branch2a", "res3a_branch1",
+              "res3b_branch2b", "res4a_branch2b", "res5a_branch2a", "res5c_branch2b", "res5c_branch2c"]
+
+
+@pytest.mark.parametrize("name", CONV_CASES)
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv_layer_matches_oracle(engine, assets, name, B):
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    g = np.random.Generator(np.random.Philox(100 + idx))
+    cin = 3 if idx == 0 else s.cin
+    x = g.normal(0, 1, (B, s.hin, s.hin, cin)).astype(np.float32)
+    use_res = name.endswith("2c")
+    res = g.normal(0, 1, (B, s.hout, s.hout, s.cout)).astype(np.float32) if use_res else None
+    y = cpu(engine.debug_conv(idx, gpu(x), residual=None if res is None else gpu(res), relu=True))
+    p = assets["enc"]
+    pad = 3 if idx == 0 else (1 if s.kh == 3 else 0)
+    ref = O.conv2d_nhwc(x, p[s.name + "/kernel"], p[s.name + "/bias"], s.stride, pad, dtype=np.float64)
+    sc, sh = _bn_fold(p, s)
+    ref = ref * sc + sh
+    if use_res:
+        ref = ref + res
+    ref = np.maximum(ref, 0)
+    assert y.shape == ref.shape
+    assert rel(y, ref) < 5e-6, name
+
+
+def test_pools(engine):
+    import ctypes as C
+
+    import torch
+
+    from hpe_amd import _lib
+
+    g = np.random.Generator(np.random.Philox(8))
+    x = np.maximum(g.normal(0, 1, (2, 112, 112, 64)), 0).astype(np.float32)
+    xt = gpu(x)
+    y = torch.empty((2, 56, 56, 64), dtype=torch.float32, device="cuda")
+    _lib.check(engine.lib.hpe_debug_maxpool(xt.data_ptr(), 2, 112, 64, y.data_ptr(), None))
+    ref = torch.nn.functional.max_pool2d(torch.nn.functional.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (1, 1, 1, 1)), 3, 2)
+    np.testing.assert_array_equal(cpu(y), ref.permute(0, 2, 3, 1).numpy())
+    z = np.asarray(g.normal(0, 1, (3, 49, 2048)), np.float32)
+    zt = gpu(z)
+    a = torch.empty((3, 2048), dtype=torch.float32, device="cuda")
+    _lib.check(engine.lib.hpe_debug_avgpool(zt.data_ptr(), 3, 49, 2048, a.data_ptr(), None))
+    assert rel(cpu(a), z.astype(np.float64).mean(1)) < 1e-6
+
+
+def test_encoder_features(engine, assets):
+    img = synthetic.make_images(2, seed=21)
+    f = cpu(engine.encoder(gpu(img)))
+    ref64 = O.resnet50_features(img, assets["enc"], dtype=np.float64)
+    ref32 = O.resnet50_features(img, assets["enc"], dtype=np.float32)
+    e_hip, e_cpu = rel(f, ref64), rel(ref32, ref64)
+    print("encoder rel err vs fp64 truth: hip %.3g, oracle-fp32 %.3g" % (e_hip, e_cpu))
+    assert e_hip < 2e-5
+    assert rel(f, ref32) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- regressor + full path
+def test_regress_stage(engine, assets):
+    g = np.random.Generator(np.random.Philox(9))
+    feat = np.abs(g.normal(0, 2, (5, 2048))).astype(np.float32)
+    th0 = np.tile(assets["mean_var"], (5, 1))
+    ref1 = th0 + O.regression_network(np.concatenate([feat, th0], 1).astype(np.float64), assets["reg"])
+    t1 = cpu(engine.regress_stage(gpu(feat)))
+    assert rel(t1, ref1) < 5e-6
+    ref2 = ref1 + O.regression_network(np.concatenate([feat, ref1], 1), assets["reg"])
+    t2 = cpu(engine.regress_stage(gpu(feat), gpu(ref1.astype(np.float32))))
+    assert rel(t2, ref2) < 5e-6
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_full_path_matches_oracle(engine, assets, B):
+    img = synthetic.make_images(B, seed=30 + B)
+    stages = engine.forward(gpu(img), all_stages=True, want=("verts", "joints", "cams", "theta", "J_transformed", "kp2d"))
+    ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"], all_stages=True)
+    for i in range(3):
+        assert rel(cpu(stages[i]["theta"]), ref["stage_theta"][i]) < TOL
+        assert rel(cpu(stages[i]["verts"]), ref["stage_verts"][i]) < TOL
+        assert rel(cpu(stages[i]["joints"]), ref["stage_joints"][i]) < TOL
+        assert rel(cpu(stages[i]["kp2d"]), ref["stage_kp2d"][i]) < TOL
+        assert rel(cpu(stages[i]["J_transformed"]), ref["stage_J_transformed"][i]) < TOL
+    last = engine.forward(gpu(img))[0]
+    for k in ("verts", "joints", "cams", "theta", "kp2d"):
+        np.testing.assert_array_equal(cpu(last[k]), cpu(stages[2][k]))
+    mpjpe = np.linalg.norm(cpu(stages[2]["joints"]) - ref["generated_joints"], axis=-1).mean()
+    print("MPJPE vs oracle (19 kp): %.3g" % mpjpe)
+    assert mpjpe < 1e-4
+
+
+class _Cfg(object):
+    img_size = 224
+    num_stage = 3
+    batch_size = 2
+    data_format = "NHWC"
+    checkpoint_dir = None
+    smpl_model_path = None
+
+
+def test_predictor_surface(assets):
+    p = hpe_amd.Predictor(_Cfg(), smpl_model=assets["smpl"], mean_params=assets["mean"], encoder_params=assets["enc"],
+                          regressor_params=assets["reg"])
+    assert (p.num_cam, p.num_theta, p.total_params, p.num_joints) == (3, 72, 85, 14)
+    np.testing.assert_array_equal(p.mean_np, assets["mean_var"])
+    img = synthetic.make_images(3, seed=41)  # 3 > batch_size 2 -> chunked
+    r = p.predict(img)
+    ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"])
+    assert set(["generated_joints", "generated_verts", "generated_cams"]) <= set(r)
+    assert tuple(r["generated_verts"].shape) == (3, 6890, 3) and tuple(r["generated_joints"].shape) == (3, 19, 3)
+    for k in ("generated_joints", "generated_verts", "generated_cams", "generated_kp2d", "theta", "J_transformed"):
+        assert rel(cpu(r[k]), ref[k]) < TOL, k
+    v, c, j = p.predict_single_image(img[0])
+    assert rel(cpu(v), ref["generated_verts"][:1]) < TOL and rel(cpu(j), ref["generated_joints"][:1]) < TOL
+    kp = p.proj_fn(r["generated_joints"], r["generated_cams"])
+    assert rel(cpu(kp), ref["generated_kp2d"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------- losses (config 5)
+def test_kp_loss(assets):
+    _, kp_gt = synthetic.make_lsp_targets(4)
+    g = np.random.Generator(np.random.Philox(12))
+    pred = g.uniform(-1, 1, (4, 19, 2)).astype(np.float32)
+    parts = cpu(hpe_amd.kp_reprojection_loss(gpu(kp_gt), gpu(pred), return_parts=True))
+    ref = O.kp_reprojection_loss(kp_gt, pred)
+    assert abs(parts[2] - ref) / abs(ref) < 1e-5
+    assert parts[1] == 2 * kp_gt[:, :, 2].sum()
+    zero = cpu(hpe_amd.kp_reprojection_loss(gpu(np.zeros((2, 19, 3), np.float32)), gpu(pred[:2])))
+    assert zero == 0.0
+
+
+def test_mesh_loss(engine, assets):
+    B = 2
+    seg, _ = synthetic.make_lsp_targets(B, seed=14)
+    seg[1, :, :, 0] *= (np.arange(224)[None, :] % 3 == 0)  # ragged: different point counts per image
+    th = synthetic.make_thetas(B, seed=15)
+    th[:, 0] = 0.8
+    v, _, _ = assets["osmpl"](th[:, 75:], th[:, 3:75], get_skin=True)
+    sil_pred = O.reproject_vertices(v, th[:, :3], np.array([224.0, 224.0], np.float32)).astype(np.float32)
+    ref = O.mesh_reprojection_loss(O.silhouette_points(seg), sil_pred, B)
+    out = float(cpu(hpe_amd.mesh_reprojection_loss(engine, gpu(seg), gpu(sil_pred))))
+    assert abs(out - ref) / abs(ref) < 1e-5, (out, ref)
