@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the per-image forward hot path (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole path over one batch of 256 synthetic 224x224x3 images per GPU, already
+resident in HBM: ResNet-50 v1 encoder (fp32 MFMA) -> 3 IEF regressor stages -> SMPL (LBS, joint regress,
+orthographic reprojection) at ALL three stages (what Trainer.val_step evaluates; nothing is skipped) ->
+for N > 1 one RCCL all-gather of the final theta [256,85] per rank over xGMI.  Images shard by batch
+(independent units, no data-path collective besides that gather): weak scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family, the implicit-GEMM convolution
+(conv_gemm_f32_kernel, 53 launches per step): achieved = 7.7119 GFLOP/img * 256 img / (sum of the 53 launch
+durations, HIP events recorded on the launch stream inside the timed region), peak = 157.3 TFLOP/s fp32 MFMA.
+`cpu_baseline` is the CPU oracle (a NumPy / torch-CPU restatement of the reference path -- TensorFlow is not
+installable here) timed on this host's cores on a bounded sample, rank 0, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENCODER_GFLOP_PER_IMG = 7.711850496  # 2 * 3,855,925,248 MAC (resnet_spec.encoder_macs_per_image)
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE metric: 256)")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="images of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import hpe_amd
+    from hpe_amd import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    smpl = synthetic.make_smpl_model()
+    enc = synthetic.make_encoder_params()
+    reg = synthetic.make_regressor_params()
+    mean_vals = synthetic.make_mean_params()
+
+    class Cfg(object):
+        img_size, num_stage, batch_size, data_format = 224, 3, B, "NHWC"
+        checkpoint_dir = smpl_model_path = None
+
+    pred = hpe_amd.Predictor(Cfg(), smpl_model=smpl, mean_params=mean_vals, encoder_params=enc, regressor_params=reg,
+                             device=local_rank)
+    eng = pred.engine
+    images = torch.from_numpy(synthetic.make_images(B, seed=1000 + rank)).cuda()
+    run, outs = eng.make_forward_plan(B, all_stages=True)
+    theta_all = torch.empty((world * B, 85), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def step():
+        o = run(images)
+        if world > 1:
+            dist.all_gather_into_tensor(theta_all, o[-1]["theta"])
+        return o
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_roofline:
+        eng.enable_timing(2)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    phase = None
+    if not args.no_roofline:
+        tm = eng.timings()  # events of the last timed step
+        conv_ms = tm["conv_ms"]
+        per_conv = eng.conv_timings()
+        achieved = ENCODER_GFLOP_PER_IMG * B / conv_ms  # GFLOP/ms == TFLOP/s
+        roofline = {
+            "bound": "mfma",
+            "kernel": "conv_gemm_f32_kernel (53 launches/step, all instantiations)",
+            "achieved": round(achieved, 3),
+            "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": None,
+            "launch_ms": round(conv_ms, 4),
+            "flop_per_launch": ENCODER_GFLOP_PER_IMG * B * 1e9,
+        }
+        phase = {"encoder_ms": round(tm["encoder_ms"], 3), "conv_ms": round(conv_ms, 3),
+                 "regress_smpl_ms": round(tm["regress_smpl_ms"], 3), "step_ms_events": round(tm["total_ms"], 3)}
+        eng.enable_timing(0)
+        if rank == 0 and os.environ.get("HPE_BENCH_LAYERS"):
+            for s, ms in zip(hpe_amd.resnet_spec.CONV_SPECS, per_conv):
+                fl = 2.0 * s.kh * s.kw * s.cin * s.cout * s.hout * s.hout * B
+                print("%-18s %8.3f ms %7.1f TF" % (s.name, ms, fl / ms / 1e9), file=sys.stderr)
+
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import hmr_oracle as O  # the checker, timed as the CPU baseline
+
+        n = args.cpu_sample
+        img_np = images[:n].cpu().numpy()
+        osmpl = O.SMPL(smpl)
+        mean = O.load_mean_param(mean_vals)
+        O.predict(img_np[:1], enc, reg, osmpl, mean)  # warm-up (thread pools, allocator)
+        tc = time.perf_counter()
+        ref = O.predict(img_np, enc, reg, osmpl, mean)
+        tcpu = time.perf_counter() - tc
+        cpu_baseline = {
+            "value": round(n / tcpu, 3),
+            "unit": "images/sec",
+            "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": "%d of the %d bench images, full path (ResNet-50 + 3 IEF stages + SMPL x3), CPU restatement of "
+                      "the reference (NumPy + torch-CPU conv2d), not TensorFlow" % (n, B),
+        }
+        j = outs[-1]["joints"][:n].cpu().numpy()
+        v = outs[-1]["verts"][:n].cpu().numpy()
+        parity = {
+            "mpjpe_vs_oracle": float(np.linalg.norm(j - ref["generated_joints"], axis=-1).mean()),
+            "verts_rel_err": float(np.abs(v - ref["generated_verts"]).max() / np.abs(ref["generated_verts"]).max()),
+        }
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        line = {
+            "metric": "images/sec (224x224, batch 256/GPU)",
+            "value": round(value, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "batch=%d/GPU 224x224x3 synthetic images, fp32 ResNet-50 v1 + 3-iter regressor + SMPL LBS at all 3 "
+                            "stages%s (BASELINE metric config: batch 256/GPU; %s)" % (B, ", RCCL all-gather of theta" if world > 1 else "", "configs[2]" if world > 1 else "configs[1] at the metric batch"),
+                "global_batch": world * B,
+                "parallelism": "dp%d (batch shard, replicated weights)" % world,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        if phase:
+            line["phase_ms"] = phase
+        if parity:
+            line["parity"] = parity
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
