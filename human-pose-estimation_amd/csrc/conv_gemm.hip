@@ -34,17 +34,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int MODE>
+// Per-thread description of one staged A row: element offset of its first k element (+ this thread's
+// 16-B chunk) and, for the 3x3 conv, a 9-bit mask of the taps that fall inside the image.
 struct RowAddr {
-    int base;    // element offset of this row's first k element (see per-mode meaning)
-    int ho, wo;  // only CONV3
+    int base;
+    unsigned mask;
 };
 
 template <int MODE>
-__device__ __forceinline__ RowAddr<MODE> make_row(const GemmArgs& p, int m, int kc4) {
-    RowAddr<MODE> r;
-    r.ho = 0;
-    r.wo = 0;
+__device__ __forceinline__ RowAddr make_row(const GemmArgs& p, int m, int kc4) {
+    RowAddr r;
+    r.mask = 0x1ffu;
     if (m >= p.M) m = p.M - 1;  // tail rows: read a valid row, the store guard drops the result
     if (MODE == GEMM_DENSE) {
         r.base = m * p.lda + kc4;
@@ -58,8 +58,13 @@ __device__ __forceinline__ RowAddr<MODE> make_row(const GemmArgs& p, int m, int 
             r.base = ((b * p.Hi + ho * p.stride) * p.Wi + wo * p.stride) * p.Cin + kc4;
         } else if (MODE == GEMM_CONV3) {
             r.base = ((b * p.Hi + ho) * p.Wi + wo) * p.Cin + kc4;
-            r.ho = ho;
-            r.wo = wo;
+            unsigned mk = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+                if ((unsigned)(ho + dh) < (unsigned)p.Hi && (unsigned)(wo + dw) < (unsigned)p.Wi) mk |= 1u << tap;
+            }
+            r.mask = mk;
         } else {  // GEMM_STEM: padded input [B,Hi,Wi,4], 8 pixels x 4 ch = one 32-float slab per kh
             r.base = ((b * p.Hi + 2 * ho) * p.Wi + 2 * wo) * 4 + kc4;
         }
@@ -67,23 +72,48 @@ __device__ __forceinline__ RowAddr<MODE> make_row(const GemmArgs& p, int m, int 
     return r;
 }
 
+// Wave-uniform position of a k-slab inside the (kh, kw, cin) axis; advanced once per slab with scalar ops.
+struct SlabPos {
+    int off;   // element offset added to every row base
+    int tap;   // CONV3: kh*3+kw
+    int cs;    // CONV3: cin slab inside the tap
+};
+
 template <int MODE>
-__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const RowAddr<MODE>& r, int slab) {
+__device__ __forceinline__ void slab_advance(const GemmArgs& p, SlabPos& sp) {
     if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
-        return *reinterpret_cast<const f32x4*>(p.x + (size_t)(r.base + slab * BK));
+        sp.off += BK;
     } else if (MODE == GEMM_CONV3) {
-        const int tap = slab / p.cin_slabs;
-        const int c0 = (slab - tap * p.cin_slabs) * BK;
-        const int kh = tap / 3;
-        const int dh = kh - 1;
-        const int dw = tap - kh * 3 - 1;
-        const bool ok = (unsigned)(r.ho + dh) < (unsigned)p.Hi && (unsigned)(r.wo + dw) < (unsigned)p.Wi;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(r.base + (dh * p.Wi + dw) * p.Cin + c0));
-        return v;
+        sp.cs += 1;
+        sp.off += BK;
+        if (sp.cs == p.cin_slabs) {
+            sp.cs = 0;
+            sp.tap += 1;
+            const int kh = sp.tap / 3;
+            sp.off = ((kh - 1) * p.Wi + (sp.tap - kh * 3 - 1)) * p.Cin;
+        }
     } else {
-        return *reinterpret_cast<const f32x4*>(p.x + (size_t)(r.base + slab * p.Wi * 4));
+        sp.off += p.Wi * 4;
     }
+}
+
+template <int MODE>
+__device__ __forceinline__ SlabPos slab_first(const GemmArgs& p) {
+    SlabPos sp;
+    sp.tap = 0;
+    sp.cs = 0;
+    sp.off = (MODE == GEMM_CONV3) ? (-p.Wi - 1) * p.Cin : 0;
+    return sp;
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const RowAddr& r, const SlabPos& sp) {
+    if (MODE == GEMM_CONV3) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((r.mask >> sp.tap) & 1u) v = *reinterpret_cast<const f32x4*>(p.x + (r.base + sp.off));
+        return v;
+    }
+    return *reinterpret_cast<const f32x4*>(p.x + (r.base + sp.off));
 }
 
 template <int MODE, int BM, int BN, int WM, int WN>
@@ -92,10 +122,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
     constexpr int NT = BN / WN / 32;
     constexpr int AP = BM / 32;  // A rows staged per thread
     constexpr int BP = BN / 32;  // W rows staged per thread
+    constexpr int EP = BN + 4;   // epilogue LDS pitch (floats)
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MT >= 1 && NT >= 1, "tile too small");
+    static_assert(BM * EP <= 2 * (BM + BN) * LDS_PITCH, "epilogue tile must fit the staging LDS");
 
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_PITCH];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_PITCH];
+    constexpr int BUF = (BM + BN) * LDS_PITCH;
 
     // XCD-aware bijective remap: blocks b, b+8, ... (one XCD) walk consecutive tiles.
     const int total = p.n_mtiles * p.n_ntiles;
@@ -117,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
     // ---- staging addresses: thread t stages 16 B (k chunk t&7) of rows (t>>3) + 32*i
     const int kc4 = (t & 7) * 4;
     const int srow = t >> 3;
-    RowAddr<MODE> arow[AP];
+    RowAddr arow[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) arow[i] = make_row<MODE>(p, m0 + srow + 32 * i, kc4);
     const float* wptr = p.w + (size_t)(n0 + srow) * p.ldw + kc4;
@@ -138,29 +171,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
 
     f32x4 ra[AP], rb[BP];
     const int S = p.K / BK;
+    SlabPos sp = slab_first<MODE>(p);
 
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], 0);
+    for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], sp);
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw);
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[0][lds_st + 32 * i * LDS_PITCH]) = ra[i];
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[lds_st + 32 * i * LDS_PITCH]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[0][lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
     __syncthreads();
 
     for (int s = 0; s < S; ++s) {
-        const int cur = s & 1;
+        const int cur = (s & 1) * BUF;
         const bool more = (s + 1) < S;
         if (more) {
+            slab_advance<MODE>(p, sp);
 #pragma unroll
-            for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], s + 1);
+            for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], sp);
 #pragma unroll
             for (int i = 0; i < BP; ++i)
                 rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw + (s + 1) * BK);
         }
-        const float* A = &lds[cur][a_off];
-        const float* B = &lds[cur][b_off];
+        const float* A = &lds[cur + a_off];
+        const float* B = &lds[cur + b_off];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 fa[MT], fb[NT];
@@ -177,36 +212,70 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            const int nxt = cur ^ 1;
+            const int nxt = BUF - cur;
 #pragma unroll
-            for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[nxt][lds_st + 32 * i * LDS_PITCH]) = ra[i];
+            for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[nxt + lds_st + 32 * i * LDS_PITCH]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < BP; ++i)
-                *reinterpret_cast<f32x4*>(&lds[nxt][lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
+            for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[nxt + lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
         }
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    const int col_l = lane & 31;
-    const int row_l = 4 * (lane >> 5);
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // BN-scale/shift is applied in registers, the tile is transposed through LDS (the staging buffers are
+    // free after the last barrier) and leaves as full rows: 16 B per lane, BN*4 contiguous bytes per row,
+    // with the residual read the same way.
+    {
+        const int col_l = lane & 31;
+        const int row_l = 4 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + (wn * NT + j) * 32 + col_l;
-        const bool n_ok = n < p.N;
-        const float sc = n_ok ? p.scale[n] : 0.f;
-        const float sh = n_ok ? p.shift[n] : 0.f;
+        for (int j = 0; j < NT; ++j) {
+            const int cl = (wn * NT + j) * 32 + col_l;
+            const int n = n0 + cl;
+            const bool n_ok = n < p.N;
+            const float sc = n_ok ? p.scale[n] : 0.f;
+            const float sh = n_ok ? p.shift[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mb = m0 + (wm * MT + i) * 32 + row_l;
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (wm * MT + i) * 32 + row_l;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (n_ok && m < p.M) {
-                    float v = acc[i][j][e] * sc + sh;
-                    if (p.res) v += p.res[(size_t)m * p.ldres + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[(size_t)m * p.ldy + n] = v;
+                for (int e = 0; e < 16; ++e) lds[(rl + (e & 3) + 8 * (e >> 2)) * EP + cl] = acc[i][j][e] * sc + sh;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int TPR = BN / 4;     // threads per output row
+        constexpr int RPP = 256 / TPR;  // rows per pass
+        const int r = t / TPR;
+        const int c4 = (t - r * TPR) * 4;
+        const int n = n0 + c4;
+        const bool full = (n + 3) < p.N;
+#pragma unroll 4
+        for (int pass = 0; pass < BM / RPP; ++pass) {
+            const int row = pass * RPP + r;
+            const int m = m0 + row;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * EP + c4]);
+            if (full) {
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n);
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (n + u < p.N) {
+                        float o = vv[u];
+                        if (p.res) o += p.res[(size_t)m * p.ldres + n + u];
+                        if (p.relu) o = fmaxf(o, 0.f);
+                        p.y[(size_t)m * p.ldy + n + u] = o;
+                    }
                 }
             }
         }
@@ -239,6 +308,10 @@ hipError_t launch_mode(GemmArgs& p, int tile, hipStream_t st) {
 hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.ldw % 4) != 0 || p.ldw < p.K) return hipErrorInvalidValue;
     if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return hipErrorInvalidValue;
+    // vector epilogue: 16-B aligned rows of y / residual
+    if ((p.ldy % 4) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
+    if (p.res && ((p.ldres % 4) != 0 || ((uintptr_t)p.res & 15) != 0)) return hipErrorInvalidValue;
+    if (((uintptr_t)p.x & 15) != 0 || ((uintptr_t)p.w & 15) != 0) return hipErrorInvalidValue;
     const int bn = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : 64;
     const int n_pad = ((p.N + bn - 1) / bn) * bn;
     if (n_pad > p.w_rows) return hipErrorInvalidValue;  // packed weights must cover the padded N tiles
