@@ -41,7 +41,8 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     tmp = LIB + ".tmp%d" % os.getpid()
-    cmd = [_hipcc()] + FLAGS + ["-o", tmp] + srcs
+    extra = os.environ.get("HPE_EXTRA_FLAGS", "").split()
+    cmd = [_hipcc()] + FLAGS + extra + ["-o", tmp] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -23,6 +23,7 @@
 //     on ONE XCD (blocks b, b+8, ... share an L2), so the panel is fetched from HBM once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hpe_internal.h"
 
@@ -109,14 +110,16 @@ __device__ __forceinline__ SlabPos slab_first(const GemmArgs& p) {
 template <int MODE>
 __device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const RowAddr& r, const SlabPos& sp) {
     if (MODE == GEMM_CONV3) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((r.mask >> sp.tap) & 1u) v = *reinterpret_cast<const f32x4*>(p.x + (r.base + sp.off));
-        return v;
+        // branch-free: out-of-image taps read the (always valid) centre pixel and are zeroed by a select
+        const bool ok = (r.mask >> sp.tap) & 1u;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (r.base + (ok ? sp.off : sp.cs * BK)));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        return ok ? v : z;
     }
     return *reinterpret_cast<const f32x4*>(p.x + (r.base + sp.off));
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN, int SCHED>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
@@ -173,31 +176,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
     const int S = p.K / BK;
     SlabPos sp = slab_first<MODE>(p);
 
+    auto load_slab = [&](int slab) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], sp);
+        for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], sp);
 #pragma unroll
-    for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw);
+        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw + slab * BK);
+    };
+    auto store_slab = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[lds_st + 32 * i * LDS_PITCH]) = ra[i];
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[buf + lds_st + 32 * i * LDS_PITCH]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
-    __syncthreads();
-
-    for (int s = 0; s < S; ++s) {
-        const int cur = (s & 1) * BUF;
-        const bool more = (s + 1) < S;
-        if (more) {
-            slab_advance<MODE>(p, sp);
+        for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[buf + lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
+    };
+    auto mma_groups = [&](int buf, int g0, int g1) {
+        const float* A = &lds[buf + a_off];
+        const float* B = &lds[buf + b_off];
 #pragma unroll
-            for (int i = 0; i < AP; ++i) ra[i] = load_a<MODE>(p, arow[i], sp);
-#pragma unroll
-            for (int i = 0; i < BP; ++i)
-                rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw + (s + 1) * BK);
-        }
-        const float* A = &lds[cur + a_off];
-        const float* B = &lds[cur + b_off];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = g0; g < g1; ++g) {
             f32x4 fa[MT], fb[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_PITCH + g * 8);
@@ -211,16 +206,188 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
         }
-        if (more) {
+    };
+
+    // Software pipeline (register staged, LDS double buffered, one barrier per slab):
+    //   iteration s multiplies LDS[s&1]; in the MIDDLE of its MFMA stream it retires the registers that hold
+    //   slab s+1 into LDS[(s+1)&1] (free since the barrier that ended iteration s-1) and immediately re-issues
+    //   the global loads of slab s+2 into the same registers, so every global load has a full iteration to land
+    //   and the LDS writes issue in the shadow of the 64-cycle MFMAs.
+#ifdef HPE_ABLATION
+    unsigned long long t_clk0 = 0, t_rt0 = 0;
+    if (p.dbg) {
+        t_clk0 = __builtin_amdgcn_s_memtime();
+        t_rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    load_slab(0);
+    store_slab(0);
+    if (S > 1) {
+        slab_advance<MODE>(p, sp);
+        load_slab(1);
+    }
+    __syncthreads();
+
+    if (SCHED == 8 || SCHED == 9) {
+        // Fully interleaved steady state, one basic block per slab.  LDS operations keep their source order
+        // (the compiler must assume the staging writes alias the fragment reads), so the source is written in
+        // the order we want them issued: per k-group g (16*MT*NT/4 MFMAs) -> prefetch the fragments of g+1,
+        // multiply g, retire 1/4 of the staged registers into the other LDS buffer and re-issue their global
+        // loads.  sched_group_barrier then pins the MFMAs between those memory instructions so that each
+        // VMEM / DS issue sits in the shadow of a 64-cycle MFMA.
+        constexpr int QA = AP / 4 > 0 ? AP / 4 : 1;  // staged A rows retired per k-group
+        constexpr int QB = BP / 4 > 0 ? BP / 4 : 1;
+        constexpr int GA = AP / QA, GB = BP / QB;    // groups that retire A / B rows (4, or 2 for 64-row tiles)
+        constexpr int MPG = 4 * MT * NT;             // MFMAs per k-group
+        int s = 0;
+        for (; s + 2 < S; ++s) {
+            const int cur = (s & 1) * BUF;
             const int nxt = BUF - cur;
+            const float* A = &lds[cur + a_off];
+            const float* B = &lds[cur + b_off];
+            slab_advance<MODE>(p, sp);
+            f32x4 fa[2][MT], fb[2][NT];
 #pragma unroll
-            for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&lds[nxt + lds_st + 32 * i * LDS_PITCH]) = ra[i];
+            for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_PITCH);
 #pragma unroll
-            for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&lds[nxt + lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];
+            for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(B + j * 32 * LDS_PITCH);
+#define HPE_KGROUP(G)                                                                                                  \
+    {                                                                                                                  \
+        if (G < 3) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) fa[(G + 1) & 1][i] =                                        \
+                *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_PITCH + (G + 1) * 8);                                 \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) fb[(G + 1) & 1][j] =                                        \
+                *reinterpret_cast<const f32x4*>(B + j * 32 * LDS_PITCH + (G + 1) * 8);                                 \
+        }                                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int i = 0; i < MT; ++i)                \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] =                                                 \
+                __builtin_amdgcn_mfma_f32_32x32x2f32(fa[G & 1][i][ks], fb[G & 1][j][ks], acc[i][j], 0, 0, 0);          \
+        if (G < GA) {                                                                                                  \
+            _Pragma("unroll") for (int q = 0; q < QA; ++q) {                                                           \
+                const int i = G * QA + q;                                                                              \
+                *reinterpret_cast<f32x4*>(&lds[nxt + lds_st + 32 * i * LDS_PITCH]) = ra[i];                            \
+                ra[i] = load_a<MODE>(p, arow[i], sp);                                                                  \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (G < GB) {                                                                                                  \
+            _Pragma("unroll") for (int q = 0; q < QB; ++q) {                                                           \
+                const int i = G * QB + q;                                                                              \
+                *reinterpret_cast<f32x4*>(&lds[nxt + lds_st + (BM + 32 * i) * LDS_PITCH]) = rb[i];                     \
+                rb[i] = *reinterpret_cast<const f32x4*>(wptr + (size_t)(32 * i) * p.ldw + (s + 2) * BK);               \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (SCHED == 9) {                                                                                              \
+            constexpr int NST = (G < GA ? QA : 0) + (G < GB ? QB : 0);                                                 \
+            if (G < 3) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                                        \
+            if constexpr (NST == 0) {                                                                                  \
+                __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);                                                   \
+            } else {                                                                                                   \
+                _Pragma("unroll") for (int q = 0; q < NST; ++q) {                                                      \
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPG / NST, 0);                                         \
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                 \
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                 \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+            HPE_KGROUP(0)
+            HPE_KGROUP(1)
+            HPE_KGROUP(2)
+            HPE_KGROUP(3)
+#undef HPE_KGROUP
+            __syncthreads();
+        }
+        for (; s < S; ++s) {
+            const int cur = (s & 1) * BUF;
+            mma_groups(cur, 0, 2);
+            if (s + 1 < S) store_slab(BUF - cur);
+            mma_groups(cur, 2, 4);
+            __syncthreads();
+        }
+    } else
+    for (int s = 0; s < S; ++s) {
+        const int cur = (s & 1) * BUF;
+        if (SCHED == 0) {
+            mma_groups(cur, 0, 2);
+            if (s + 1 < S) {
+                store_slab(BUF - cur);
+                if (s + 2 < S) {
+                    slab_advance<MODE>(p, sp);
+                    load_slab(s + 2);
+                }
+            }
+            mma_groups(cur, 2, 4);
+        } else if (SCHED == 1) {
+            mma_groups(cur, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S) {
+                store_slab(BUF - cur);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 2 < S) {
+                    slab_advance<MODE>(p, sp);
+                    load_slab(s + 2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_groups(cur, 2, 4);
+        } else if (SCHED == 6) {  // ablation: global loads, no LDS writes
+            if (s + 2 < S) {
+                slab_advance<MODE>(p, sp);
+                load_slab(s + 2);
+            }
+            mma_groups(cur, 0, 4);
+#pragma unroll
+            for (int i = 0; i < AP; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+            for (int i = 0; i < BP; ++i) asm volatile("" ::"v"(rb[i]));
+        } else if (SCHED == 7) {  // ablation: LDS writes, no global loads
+            mma_groups(cur, 0, 2);
+            if (s + 1 < S) store_slab(BUF - cur);
+            mma_groups(cur, 2, 4);
+        } else if (SCHED == 3) {  // ablation: no global loads / LDS writes in the loop (wrong results)
+            mma_groups(cur, 0, 4);
+        } else if (SCHED == 4) {  // ablation: 3 + no barrier
+            mma_groups(0, 0, 4);
+            continue;
+        } else if (SCHED == 5) {  // ablation: MFMA only, operands fixed in registers
+            f32x4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = ra[i % AP];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = rb[j % BP];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+            continue;
+        } else {
+            mma_groups(cur, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S) store_slab(BUF - cur);
+            mma_groups(cur, 1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < S) {
+                slab_advance<MODE>(p, sp);
+                load_slab(s + 2);
+            }
+            mma_groups(cur, 2, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_groups(cur, 3, 4);
         }
         __syncthreads();
     }
 
+#ifdef HPE_ABLATION
+    if (p.dbg && t == 0) {
+        p.dbg[2 * bid] = __builtin_amdgcn_s_memtime() - t_clk0;
+        p.dbg[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - t_rt0;
+    }
+#endif
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // BN-scale/shift is applied in registers, the tile is transposed through LDS (the staging buffers are
     // free after the last barrier) and leaves as full rows: 16 B per lane, BN*4 contiguous bytes per row,
@@ -282,12 +449,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+int sched_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HPE_SCHED");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 9) v = 0;
+    }
+    return v;
+}
+
 template <int MODE, int BM, int BN, int WM, int WN>
 hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
     p.n_mtiles = (p.M + BM - 1) / BM;
     p.n_ntiles = (p.N + BN - 1) / BN;
     const int grid = p.n_mtiles * p.n_ntiles;
-    hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
+    switch (sched_variant()) {
+        case 1: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 1>), dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 2>), dim3(grid), dim3(256), 0, st, p); break;
+#ifdef HPE_ABLATION
+        case 3: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 3>), dim3(grid), dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 4>), dim3(grid), dim3(256), 0, st, p); break;
+        case 5: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 5>), dim3(grid), dim3(256), 0, st, p); break;
+        case 6: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 6>), dim3(grid), dim3(256), 0, st, p); break;
+        case 7: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 7>), dim3(grid), dim3(256), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 8>), dim3(grid), dim3(256), 0, st, p); break;
+        case 9: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 9>), dim3(grid), dim3(256), 0, st, p); break;
+#endif
+        default: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 0>), dim3(grid), dim3(256), 0, st, p); break;
+    }
     return hipGetLastError();
 }
 

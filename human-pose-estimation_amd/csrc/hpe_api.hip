@@ -122,6 +122,7 @@ struct hpe_ctx {
     float *padded = nullptr, *X0 = nullptr, *X1 = nullptr, *T1 = nullptr, *T2 = nullptr, *SC = nullptr;
     float *feat = nullptr, *P1 = nullptr, *H1 = nullptr, *H2 = nullptr, *thA = nullptr, *thB = nullptr;
     float* loss_ws = nullptr;
+    unsigned long long* dbg = nullptr;  // diagnostics buffer (hpe_debug_set_dbg)
     size_t loss_ws_floats = 0;
     std::vector<void*> allocs;
     // timing
@@ -705,6 +706,38 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
         in = c->padded;
     }
     HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st));
+    return HPE_OK;
+}
+
+int hpe_debug_gemm(hpe_ctx* c, const float* x, const float* wt, int M, int N, int K, int w_rows, int tile, const float* residual,
+                   int relu, float* y, void* stream) {
+    if (!c || !c->finalized || !c->have_regressor) return fail(HPE_ERR_STATE, "needs a finalized ctx with the regressor loaded");
+    if (!x || !wt || !y || N > 1024) return fail(HPE_ERR_INVALID, "bad argument (N <= 1024)");
+    DeviceGuard g(c->cfg.device);
+    GemmArgs p{};
+    p.x = x;
+    p.w = wt;
+    p.scale = c->ones;
+    p.shift = c->zeros;
+    p.res = residual;
+    p.y = y;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.lda = K;
+    p.ldw = K;
+    p.w_rows = w_rows;
+    p.ldy = N;
+    p.ldres = N;
+    p.relu = relu;
+    p.dbg = c->dbg;
+    HIP_TRY(hpe_launch_gemm(p, GEMM_DENSE, tile, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_debug_set_dbg(hpe_ctx* c, void* dbg_dev) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    c->dbg = static_cast<unsigned long long*>(dbg_dev);
     return HPE_OK;
 }
 

@@ -19,6 +19,7 @@ struct GemmArgs {
     int relu;
     int Hi, Wi, Cin, Ho, Wo, stride, cin_slabs;
     int n_mtiles, n_ntiles;  // filled by the launcher
+    unsigned long long* dbg;  // diagnostics only (HPE_ABLATION builds): per-workgroup {shader clocks, 100 MHz ticks}
 };
 
 hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st);

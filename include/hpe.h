@@ -143,6 +143,13 @@ int hpe_mesh_loss(hpe_ctx* ctx, const float* seg_dev, const float* verts2d_dev, 
  * post-ReLU conv1 output [B,112,112,64]. */
 int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float* residual_dev, int relu, float* y_dev,
                    void* stream);
+/* Raw GEMM through the conv kernel (dense mode): y[M,N] = act(x[M,K] . wt[n][k]^T (+ residual)), wt has w_rows >= N
+ * rounded up to the tile width rows of K floats; K % 32 == 0; tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 64x128. */
+int hpe_debug_gemm(hpe_ctx* ctx, const float* x_dev, const float* wt_dev, int M, int N, int K, int w_rows, int tile,
+                   const float* residual_dev, int relu, float* y_dev, void* stream);
+/* Diagnostics builds only (-DHPE_ABLATION): device buffer of 2 x u64 per workgroup that hpe_debug_gemm fills with
+ * {shader-clock cycles, 100 MHz ticks} of the main loop; NULL disables. */
+int hpe_debug_set_dbg(hpe_ctx* ctx, void* dbg_dev);
 /* ZeroPad(1)+MaxPool3x3/2: x [B,H,H,C] -> y [B,H/2,H/2,C];  global average pool x [B,HW,C] -> y [B,C] */
 int hpe_debug_maxpool(const float* x_dev, int B, int H, int C, float* y_dev, void* stream);
 int hpe_debug_avgpool(const float* x_dev, int B, int HW, int C, float* y_dev, void* stream);

@@ -259,3 +259,42 @@ def test_mesh_loss(engine, assets):
     ref = O.mesh_reprojection_loss(O.silhouette_points(seg), sil_pred, B)
     out = float(cpu(hpe_amd.mesh_reprojection_loss(engine, gpu(seg), gpu(sil_pred))))
     assert abs(out - ref) / abs(ref) < 1e-5, (out, ref)
+
+
+# ------------------------------------------------------------------------------------------- full size (B = 256) properties
+def test_full_size_batch_invariance_and_linearity(assets):
+    """BASELINE full size (256 images / GPU): the oracle is too slow there, so check size-independent properties:
+    (1) images are independent units -- rows of a 256-batch equal the same images run in a batch of 2;
+    (2) SMPL at theta = 0 is affine in beta: verts(b1 + b2) + verts(0) == verts(b1) + verts(b2)."""
+    import torch
+
+    eng = hpe_amd.HpeEngine(device=0, max_batch=256)
+    eng.load_smpl(assets["smpl"])
+    eng.load_encoder(assets["enc"])
+    eng.load_regressor(assets["reg"])
+    eng.load_mean_theta(assets["mean_var"])
+    eng.finalize()
+    img = torch.from_numpy(synthetic.make_images(256, seed=555)).cuda()
+    big = eng.forward(img, all_stages=True)
+    pick = [0, 129, 255]
+    small = eng.forward(img[pick[1:]].contiguous(), all_stages=True)
+    for st in range(3):
+        for k in ("theta", "verts", "joints", "kp2d"):
+            a = cpu(big[st][k])[pick[1:]]
+            b = cpu(small[st][k])
+            assert rel(a, b) < 1e-6, (st, k)
+    ref = O.predict(cpu(img[:1]), assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"])
+    assert rel(cpu(big[2]["verts"])[:1], ref["generated_verts"]) < TOL
+    g = np.random.Generator(np.random.Philox(31))
+    b1 = g.normal(0, 1, (256, 10)).astype(np.float32)
+    b2 = g.normal(0, 1, (256, 10)).astype(np.float32)
+
+    def verts_of(beta):
+        th = np.zeros((256, 85), np.float32)
+        th[:, 75:] = beta
+        return cpu(eng.smpl(gpu(th), want=("verts",))["verts"]).astype(np.float64)
+
+    lhs = verts_of(b1 + b2) + verts_of(np.zeros_like(b1))
+    rhs = verts_of(b1) + verts_of(b2)
+    assert rel(lhs, rhs) < 2e-6
+    eng.close()
