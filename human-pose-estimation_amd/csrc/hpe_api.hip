@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -125,6 +126,10 @@ struct hpe_ctx {
     unsigned long long* dbg = nullptr;  // diagnostics buffer (hpe_debug_set_dbg)
     size_t loss_ws_floats = 0;
     std::vector<void*> allocs;
+    // batch-chunk streams
+    int n_streams = 1;
+    hipStream_t aux[3]{};
+    hipEvent_t ev_fork{}, ev_join[3]{};
     // timing
     int timing = 0;
     hipEvent_t ev[8]{};
@@ -254,34 +259,68 @@ hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* r
     return hipSuccess;
 }
 
-hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
-    HIPE(hpe_launch_pad_input(images, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
-    HIPE(timed_conv(c, 0, c->padded, B, nullptr, 1, c->SC, st));
-    HIPE(hpe_launch_maxpool(c->SC, c->X0, B, 112, 64, st));
-    float* cur = c->X0;
-    float* nxt = c->X1;
+// the encoder on images [i0, i0+B) of the batch (all workspace buffers are image-major)
+hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* features, int ldfeat, hipStream_t st) {
+    const size_t o_img = (size_t)i0 * HPE_IMG_SIZE * HPE_IMG_SIZE * 3;
+    const size_t o_pad = (size_t)i0 * STEM_HP * STEM_WP * 4;
+    const size_t o_big = (size_t)i0 * 802816;
+    const size_t o_mid = (size_t)i0 * 200704;
+    float* padded = c->padded + o_pad;
+    float* SC = c->SC + o_big;
+    float* T1 = c->T1 + o_mid;
+    float* T2 = c->T2 + o_mid;
+    HIPE(hpe_launch_pad_input(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
+    HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
+    HIPE(hpe_launch_maxpool(SC, c->X0 + o_big, B, 112, 64, st));
+    float* cur = c->X0 + o_big;
+    float* nxt = c->X1 + o_big;
     int ci = 1;
     const int nblk[4] = {3, 4, 6, 3};
     for (int stg = 0; stg < 4; ++stg) {
         for (int b = 0; b < nblk[stg]; ++b) {
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
-            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, c->T1, st));
-            HIPE(timed_conv(c, i2b, c->T1, B, nullptr, 1, c->T2, st));
+            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st));
+            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st));
             const float* res = cur;
             if (first) {
                 // projection shortcut (conv_block), no ReLU before the add
-                HIPE(timed_conv(c, i1, cur, B, nullptr, 0, c->SC, st));
-                res = c->SC;
+                HIPE(timed_conv(c, i1, cur, B, nullptr, 0, SC, st));
+                res = SC;
             }
-            HIPE(timed_conv(c, i2c, c->T2, B, res, 1, nxt, st));
+            HIPE(timed_conv(c, i2c, T2, B, res, 1, nxt, st));
             ci += first ? 4 : 3;
             float* t = cur;
             cur = nxt;
             nxt = t;
         }
     }
-    return hpe_launch_avgpool(cur, features, B, 49, HPE_FEATURE_DIM, ldfeat, st);
+    return hpe_launch_avgpool(cur, features + (size_t)i0 * ldfeat, B, 49, HPE_FEATURE_DIM, ldfeat, st);
+}
+
+// Batch chunks run on separate HIP streams (fork/join with events around the caller's stream): images are
+// independent, so while one chunk's launch drains its last partial round of workgroups (49*2^k tiles never fill
+// 256 CUs x 2 evenly) the other chunk's kernels fill the idle CUs.  Per-conv event timing (level 2) needs
+// back-to-back launches on one stream and therefore runs unchunked.
+hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
+    int nchunk = c->n_streams;
+    if (c->timing >= 2 || nchunk < 2 || B < 2 * 32) nchunk = 1;
+    if (nchunk == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
+    HIPE(hipEventRecord(c->ev_fork, st));
+    const int per = (B + nchunk - 1) / nchunk;
+    for (int k = 0; k < nchunk; ++k) {
+        const int i0 = k * per;
+        const int n = (i0 + per <= B) ? per : (B - i0);
+        if (n <= 0) break;
+        hipStream_t s = (k == 0) ? st : c->aux[k - 1];
+        if (k > 0) HIPE(hipStreamWaitEvent(s, c->ev_fork, 0));
+        HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s));
+        if (k > 0) {
+            HIPE(hipEventRecord(c->ev_join[k - 1], s));
+            HIPE(hipStreamWaitEvent(st, c->ev_join[k - 1], 0));
+        }
+    }
+    return hipSuccess;
 }
 
 // one IEF step on padded theta rows [B, THETA_LD]; P1 = features . W1[:2048] must be current
@@ -357,6 +396,9 @@ int hpe_destroy(hpe_ctx* c) {
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->ev_ok) {
+        for (int i = 0; i < c->n_streams - 1; ++i) (void)hipStreamDestroy(c->aux[i]);
+        (void)hipEventDestroy(c->ev_fork);
+        for (auto& e : c->ev_join) (void)hipEventDestroy(e);
         for (auto& e : c->ev) (void)hipEventDestroy(e);
         for (auto& e : c->cev0) (void)hipEventDestroy(e);
         for (auto& e : c->cev1) (void)hipEventDestroy(e);
@@ -576,6 +618,16 @@ int hpe_finalize(hpe_ctx* c) {
             if ((rc = dev_alloc(c, &c->work.verts_tmp, B * HPE_NUM_VERTS * 3, false))) return rc;
         }
         c->work.Bpad = (int)Bpad;
+    }
+    {
+        const char* e = getenv("HPE_STREAMS");
+        int ns = e ? atoi(e) : 3;
+        if (ns < 1) ns = 1;
+        if (ns > 4) ns = 4;
+        c->n_streams = ns;
+        for (int i = 0; i < ns - 1; ++i) HIP_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (auto& ev : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->cev0) HIP_TRY(hipEventCreate(&e));

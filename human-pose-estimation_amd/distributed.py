@@ -88,6 +88,11 @@ def reduce_kp_loss(parts_local):
     return torch.where(nc[1] > 0, nc[0] / torch.clamp(nc[1], min=1.0), torch.zeros_like(nc[0]))
 
 
+def reduce_losses(parts_local, mesh_local):
+    """reduce_fn for Predictor.val_step: global kp loss (numerator / count reduced separately) and mesh-loss sum."""
+    return reduce_kp_loss(parts_local), (None if mesh_local is None else reduce_sum(mesh_local))
+
+
 def reduce_sum(x):
     dist = _dist()
     x = x.clone()

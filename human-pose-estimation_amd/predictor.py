@@ -165,6 +165,47 @@ class Predictor(object):
             result["stages"] = stages
         return result
 
+    def val_step(self, images, seg_gts, kp2d_gts, use_mesh_repro_loss=True, kpr_loss_weight=60.0, mr_loss_weight=0.001,
+                 reduce_fn=None):
+        """Forward + reprojection losses of every IEF stage, i.e. the critic-free part of the reference's
+        ``Trainer.val_step`` (src/trainer.py:226-348; BASELINE config 5): per stage
+        ``kpr = 60 * kp_reprojection_loss(kp2d_gts, proj_fn(joints, cams))`` (:274-281) and
+        ``mr = 0.001 * mesh_reprojection_loss(where(seg > 0), reproject_vertices(verts, cams, [224, 224]), B)``
+        (:285-296).  ``reduce_fn(parts, mesh)`` (see distributed.py) lets ranks reduce the kp (numerator, count)
+        and the mesh sum before the division; default is single-process."""
+        import torch
+
+        from .ops import kp_reprojection_loss
+
+        images = self._to_device(images)
+        seg = self._to_device(seg_gts)
+        if seg.dim() == 4:
+            seg = seg[..., 0]
+        seg = seg.contiguous()
+        kp_gt = self._to_device(kp2d_gts).contiguous()
+        B = images.shape[0]
+        if B > self.batch_size:
+            raise ValueError("val_step needs B <= config.batch_size")
+        want = ("verts", "joints", "cams", "theta", "kp2d") + (("verts2d",) if use_mesh_repro_loss else ())
+        stages = self.engine.forward(images, all_stages=True, want=want)
+        kpr, mr = [], []
+        for st in stages:
+            parts = kp_reprojection_loss(kp_gt, st["kp2d"], return_parts=True)
+            mesh = self.engine.mesh_loss(seg, st["verts2d"]) if use_mesh_repro_loss else None
+            if reduce_fn is not None:
+                loss_kp, mesh = reduce_fn(parts, mesh)
+            else:
+                loss_kp = parts[2]
+            kpr.append(loss_kp * kpr_loss_weight)
+            if use_mesh_repro_loss:
+                mr.append(mesh * mr_loss_weight)
+        result = {"kpr_losses": kpr, "pred_keypoints": torch.stack([s["kp2d"] for s in stages], 1),
+                  "generated_verts": torch.stack([s["verts"] for s in stages], 1),
+                  "generated_cams": torch.stack([s["cams"] for s in stages], 1)}
+        if use_mesh_repro_loss:
+            result["mr_losses"] = mr
+        return result
+
     def predict_single_image(self, image):
         """reference: src/predictor.py:160-163"""
         image = self._to_device(image)

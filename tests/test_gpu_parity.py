@@ -261,6 +261,26 @@ def test_mesh_loss(engine, assets):
     assert abs(out - ref) / abs(ref) < 1e-5, (out, ref)
 
 
+def test_val_step_losses_match_oracle(assets):
+    cfg = _Cfg()
+    cfg.batch_size = 3
+    p = hpe_amd.Predictor(cfg, smpl_model=assets["smpl"], mean_params=assets["mean"], encoder_params=assets["enc"],
+                          regressor_params=assets["reg"])
+    img = synthetic.make_images(3, seed=51)
+    seg, kp_gt = synthetic.make_lsp_targets(3, seed=52)
+    seg[2] = 0.0
+    seg[2, 100:120, 90:130] = 1.0
+    r = p.val_step(img, seg, kp_gt)
+    ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"], all_stages=True)
+    lo = O.val_losses(ref["stage_verts"], ref["stage_cams"], ref["stage_kp2d"], seg, kp_gt)
+    for i in range(3):
+        a, b = float(r["kpr_losses"][i]), float(lo["kpr_losses"][i])
+        assert abs(a - b) / abs(b) < 1e-4, (i, a, b)
+        a, b = float(r["mr_losses"][i]), float(lo["mr_losses"][i])
+        assert abs(a - b) / abs(b) < 1e-4, (i, a, b)
+    assert tuple(r["pred_keypoints"].shape) == (3, 3, 19, 2) and tuple(r["generated_verts"].shape) == (3, 3, 6890, 3)
+
+
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
 def test_full_size_batch_invariance_and_linearity(assets):
     """BASELINE full size (256 images / GPU): the oracle is too slow there, so check size-independent properties:
