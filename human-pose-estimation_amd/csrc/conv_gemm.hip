@@ -449,6 +449,201 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA staged variant: `global_load_lds_dwordx4` writes each 16-B chunk straight into LDS (no VGPR round trip,
+// no ds_write).  A wave-instruction fills 1 KiB = 8 unpadded 128-B rows; the bank spread the padded pitch gave the
+// register-staged kernel comes from an XOR swizzle applied on the per-lane SOURCE address instead:
+// LDS chunk c of row r holds logical chunk c ^ ((r >> 1) & 7), and the fragment read applies the same XOR, which
+// makes every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row.
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int AP = BM / 32;
+    constexpr int BP = BN / 32;
+    constexpr int EP = BN + 4;
+    constexpr int BUF = (BM + BN) * BK;  // floats per staging buffer (unpadded rows)
+    constexpr int LDS_FLOATS = (2 * BUF > BM * EP) ? 2 * BUF : BM * EP;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int total = p.n_mtiles * p.n_ntiles;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int mtile = swz / p.n_ntiles;
+    const int ntile = swz - mtile * p.n_ntiles;
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+
+    // ---- DMA sources: instruction i of wave w fills rows (4i + w) * 8 + (lane >> 3), LDS chunk lane & 7
+    const int drow = lane >> 3;
+    RowAddr arow[AP];
+    const float* wsrc[BP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int r = (4 * i + wave) * 8 + drow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        arow[i] = make_row<MODE>(p, m0 + r, lc * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int r = (4 * i + wave) * 8 + drow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[i] = p.w + (size_t)(n0 + r) * p.ldw + lc * 4;
+    }
+
+    // ---- fragment read offsets: row r of the wave tile, logical chunk 2g + (lane >> 5)
+    int a_row[MT], b_row[NT], a_x[MT], b_x[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = (wm * MT + i) * 32 + (lane & 31);
+        a_row[i] = r * BK;
+        a_x[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = (wn * NT + j) * 32 + (lane & 31);
+        b_row[j] = (BM + r) * BK;
+        b_x[j] = (r >> 1) & 7;
+    }
+    const int hi = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int S = p.K / BK;
+    SlabPos sp = slab_first<MODE>(p);
+
+    auto issue_dma = [&](int slab, int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const float* src;
+            if (MODE == GEMM_CONV3) {
+                const bool ok = (arow[i].mask >> sp.tap) & 1u;
+                src = ok ? (p.x + (arow[i].base + sp.off)) : p.zero;
+            } else {
+                src = p.x + (arow[i].base + sp.off);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (4 * i + wave) * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + slab * BK),
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (BM + (4 * i + wave) * 8) * BK), 16, 0,
+                                             0);
+        }
+    };
+
+    issue_dma(0, 0);
+    __syncthreads();  // emits s_waitcnt vmcnt(0) before the barrier: the DMA has landed for every wave
+
+    for (int s = 0; s < S; ++s) {
+        const int cur = (s & 1) * BUF;
+        if (s + 1 < S) {
+            slab_advance<MODE>(p, sp);
+            issue_dma(s + 1, BUF - cur);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 fa[MT], fb[NT];
+            const int lc = 2 * g + hi;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&lds[cur + a_row[i] + ((lc ^ a_x[i]) << 2)]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&lds[cur + b_row[j] + ((lc ^ b_x[j]) << 2)]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to the register-staged kernel)
+    {
+        const int col_l = lane & 31;
+        const int row_l = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cl = (wn * NT + j) * 32 + col_l;
+            const int n = n0 + cl;
+            const bool n_ok = n < p.N;
+            const float sc = n_ok ? p.scale[n] : 0.f;
+            const float sh = n_ok ? p.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (wm * MT + i) * 32 + row_l;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) lds[(rl + (e & 3) + 8 * (e >> 2)) * EP + cl] = acc[i][j][e] * sc + sh;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int TPR = BN / 4;
+        constexpr int RPP = 256 / TPR;
+        const int r = t / TPR;
+        const int c4 = (t - r * TPR) * 4;
+        const int n = n0 + c4;
+        const bool full = (n + 3) < p.N;
+#pragma unroll 4
+        for (int pass = 0; pass < BM / RPP; ++pass) {
+            const int row = pass * RPP + r;
+            const int m = m0 + row;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * EP + c4]);
+            if (full) {
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n);
+                if (p.relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (n + u < p.N) {
+                        float o = vv[u];
+                        if (p.res) o += p.res[(size_t)m * p.ldres + n + u];
+                        if (p.relu) o = fmaxf(o, 0.f);
+                        p.y[(size_t)m * p.ldy + n + u] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int stage_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HPE_STAGE");
+        v = (e && e[0] == 'r') ? 0 : 1;  // "reg" = register staged, default = LDS-DMA
+    }
+    return v;
+}
+
 int sched_variant() {
     static int v = -1;
     if (v < 0) {
@@ -464,6 +659,10 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
     p.n_mtiles = (p.M + BM - 1) / BM;
     p.n_ntiles = (p.N + BN - 1) / BN;
     const int grid = p.n_mtiles * p.n_ntiles;
+    if (stage_variant() == 1 && p.zero) {
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     switch (sched_variant()) {
         case 1: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 1>), dim3(grid), dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 2>), dim3(grid), dim3(256), 0, st, p); break;

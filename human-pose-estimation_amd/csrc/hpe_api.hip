@@ -214,6 +214,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     p.stride = s.stride;
     p.cin_slabs = s.cin / 32;
     p.lda = s.cin;
+    p.zero = c->zeros;
     int mode;
     if (idx == 0) {
         mode = GEMM_STEM;
@@ -233,6 +234,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
 hipError_t run_dense(const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
                      const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
     GemmArgs p{};
+    p.zero = shift;  // any readable 16 B: dense mode never takes the zero-page path
     p.x = x;
     p.w = w;
     p.scale = scale;
@@ -782,6 +784,7 @@ int hpe_debug_gemm(hpe_ctx* c, const float* x, const float* wt, int M, int N, in
     p.ldy = N;
     p.ldres = N;
     p.relu = relu;
+    p.zero = c->zeros;
     p.dbg = c->dbg;
     HIP_TRY(hpe_launch_gemm(p, GEMM_DENSE, tile, static_cast<hipStream_t>(stream)));
     return HPE_OK;

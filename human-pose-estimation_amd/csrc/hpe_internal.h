@@ -19,6 +19,7 @@ struct GemmArgs {
     int relu;
     int Hi, Wi, Cin, Ho, Wo, stride, cin_slabs;
     int n_mtiles, n_ntiles;  // filled by the launcher
+    const float* zero;       // >= 16 B of zeros in global memory (source of out-of-image taps for the LDS-DMA path)
     unsigned long long* dbg;  // diagnostics only (HPE_ABLATION builds): per-workgroup {shader clocks, 100 MHz ticks}
 };
 
