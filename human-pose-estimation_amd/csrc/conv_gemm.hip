@@ -456,15 +456,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
 // LDS chunk c of row r holds logical chunk c ^ ((r >> 1) & 7), and the fragment read applies the same XOR, which
 // makes every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row.
 template <int MODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
-    constexpr int AP = BM / 32;
-    constexpr int BP = BN / 32;
+    constexpr int NW = WM * WN;        // waves per workgroup (4 or 8)
+    constexpr int NTHR = 64 * NW;
+    constexpr int AP = BM / (8 * NW);  // DMA instructions per wave for the A rows of one slab
+    constexpr int BP = BN / (8 * NW);
     constexpr int EP = BN + 4;
     constexpr int BUF = (BM + BN) * BK;  // floats per staging buffer (unpadded rows)
     constexpr int LDS_FLOATS = (2 * BUF > BM * EP) ? 2 * BUF : BM * EP;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(AP >= 1 && BP >= 1, "tile too small for the wave count");
 
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -490,13 +493,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
     const float* wsrc[BP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int r = (4 * i + wave) * 8 + drow;
+        const int r = (NW * i + wave) * 8 + drow;
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
         arow[i] = make_row<MODE>(p, m0 + r, lc * 4);
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-        const int r = (4 * i + wave) * 8 + drow;
+        const int r = (NW * i + wave) * 8 + drow;
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
         wsrc[i] = p.w + (size_t)(n0 + r) * p.ldw + lc * 4;
     }
@@ -539,12 +542,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
                 src = p.x + (arow[i].base + sp.off);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + buf + (4 * i + wave) * 8 * BK), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (NW * i + wave) * 8 * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + slab * BK),
-                                             (__attribute__((address_space(3))) void*)(lds + buf + (BM + (4 * i + wave) * 8) * BK), 16, 0,
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (BM + (NW * i + wave) * 8) * BK), 16, 0,
                                              0);
         }
     };
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
     __syncthreads();
     {
         constexpr int TPR = BN / 4;
-        constexpr int RPP = 256 / TPR;
+        constexpr int RPP = NTHR / TPR;
         const int r = t / TPR;
         const int c4 = (t - r * TPR) * 4;
         const int n = n0 + c4;
@@ -659,6 +662,10 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
     p.n_mtiles = (p.M + BM - 1) / BM;
     p.n_ntiles = (p.N + BN - 1) / BN;
     const int grid = p.n_mtiles * p.n_ntiles;
+    if constexpr (WM * WN == 8) {
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(512), 0, st, p);
+        return hipGetLastError();
+    } else {
     if (stage_variant() == 1 && p.zero) {
         hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
         return hipGetLastError();
@@ -678,6 +685,7 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
         default: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 0>), dim3(grid), dim3(256), 0, st, p); break;
     }
     return hipGetLastError();
+    }
 }
 
 template <int MODE>
@@ -687,6 +695,9 @@ hipError_t launch_mode(GemmArgs& p, int tile, hipStream_t st) {
         case TILE_128x64: return launch_cfg<MODE, 128, 64, 2, 2>(p, st);
         case TILE_64x64: return launch_cfg<MODE, 64, 64, 2, 2>(p, st);
         case TILE_64x128: return launch_cfg<MODE, 64, 128, 2, 2>(p, st);
+        case TILE_128x128_W8: return launch_cfg<MODE, 128, 128, 2, 4>(p, st);
+        case TILE_128x64_W8: return launch_cfg<MODE, 128, 64, 4, 2>(p, st);
+        case TILE_256x128_W8: return launch_cfg<MODE, 256, 128, 4, 2>(p, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -701,7 +712,7 @@ hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st) {
     if ((p.ldy % 4) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
     if (p.res && ((p.ldres % 4) != 0 || ((uintptr_t)p.res & 15) != 0)) return hipErrorInvalidValue;
     if (((uintptr_t)p.x & 15) != 0 || ((uintptr_t)p.w & 15) != 0) return hipErrorInvalidValue;
-    const int bn = (tile == TILE_128x128 || tile == TILE_64x128) ? 128 : 64;
+    const int bn = (tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x128_W8 || tile == TILE_256x128_W8) ? 128 : 64;
     const int n_pad = ((p.N + bn - 1) / bn) * bn;
     if (n_pad > p.w_rows) return hipErrorInvalidValue;  // packed weights must cover the padded N tiles
     switch (mode) {

@@ -128,6 +128,7 @@ struct hpe_ctx {
     std::vector<void*> allocs;
     // batch-chunk streams
     int n_streams = 1;
+    int chunk_images = 0;
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
     // timing
@@ -168,18 +169,22 @@ int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
 
 int pick_tile(int M, int N) {
     // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
-    const bool wide = N > 64;
-    struct Cand {
-        int tile, bm, bn;
-    };
-    const Cand wide_c[] = {{TILE_128x128, 128, 128}, {TILE_64x128, 64, 128}, {TILE_64x64, 64, 64}};
-    const Cand narrow_c[] = {{TILE_128x64, 128, 64}, {TILE_64x64, 64, 64}};
-    const Cand* cs = wide ? wide_c : narrow_c;
-    const int nc = wide ? 3 : 2;
-    for (int i = 0; i < nc; ++i) {
-        const long tiles = (long)((M + cs[i].bm - 1) / cs[i].bm) * ((N + cs[i].bn - 1) / cs[i].bn);
-        if (tiles >= 512 || i == nc - 1) return cs[i].tile;
+    static int force_wide = -2, force_narrow = -2;
+    if (force_wide == -2) {
+        const char* e = getenv("HPE_TILE_WIDE");
+        force_wide = e ? atoi(e) : -1;
+        e = getenv("HPE_TILE_NARROW");
+        force_narrow = e ? atoi(e) : -1;
     }
+    const bool wide = N > 64;
+    if (wide && force_wide >= 0) return force_wide;
+    if (!wide && force_narrow >= 0) return force_narrow;
+    // Measured on MI355X (profiles/r01/d_tile_sweep.txt): with LDS-DMA staging the small tiles with 3-5 workgroups
+    // per CU beat 128x128 at 2 per CU except on the huge-M layers of stages 2-3.
+    if (!wide) return TILE_128x64;
+    const long big = (long)((M + 63) / 64) * ((N + 127) / 128);
+    if (M >= 150000) return TILE_64x128;
+    (void)big;
     return TILE_64x64;
 }
 
@@ -305,22 +310,25 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
 // 256 CUs x 2 evenly) the other chunk's kernels fill the idle CUs.  Per-conv event timing (level 2) needs
 // back-to-back launches on one stream and therefore runs unchunked.
 hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
-    int nchunk = c->n_streams;
-    if (c->timing >= 2 || nchunk < 2 || B < 2 * 32) nchunk = 1;
-    if (nchunk == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
+    int nstream = c->n_streams;
+    if (c->timing >= 2 || nstream < 2 || B < 2 * 32) nstream = 1;
+    if (nstream == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
+    // chunk size: HPE_CHUNK images (default: one chunk per stream); chunks go round-robin over the streams
+    int per = (B + nstream - 1) / nstream;
+    if (c->chunk_images > 0 && c->chunk_images < per) per = c->chunk_images;
+    const int nchunk = (B + per - 1) / per;
     HIPE(hipEventRecord(c->ev_fork, st));
-    const int per = (B + nchunk - 1) / nchunk;
+    for (int k = 1; k < nstream; ++k) HIPE(hipStreamWaitEvent(c->aux[k - 1], c->ev_fork, 0));
     for (int k = 0; k < nchunk; ++k) {
         const int i0 = k * per;
         const int n = (i0 + per <= B) ? per : (B - i0);
-        if (n <= 0) break;
-        hipStream_t s = (k == 0) ? st : c->aux[k - 1];
-        if (k > 0) HIPE(hipStreamWaitEvent(s, c->ev_fork, 0));
+        const int sid = k % nstream;
+        hipStream_t s = (sid == 0) ? st : c->aux[sid - 1];
         HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s));
-        if (k > 0) {
-            HIPE(hipEventRecord(c->ev_join[k - 1], s));
-            HIPE(hipStreamWaitEvent(st, c->ev_join[k - 1], 0));
-        }
+    }
+    for (int k = 1; k < nstream; ++k) {
+        HIPE(hipEventRecord(c->ev_join[k - 1], c->aux[k - 1]));
+        HIPE(hipStreamWaitEvent(st, c->ev_join[k - 1], 0));
     }
     return hipSuccess;
 }
@@ -627,6 +635,8 @@ int hpe_finalize(hpe_ctx* c) {
         if (ns < 1) ns = 1;
         if (ns > 4) ns = 4;
         c->n_streams = ns;
+        e = getenv("HPE_CHUNK");
+        c->chunk_images = e ? atoi(e) : 0;
         for (int i = 0; i < ns - 1; ++i) HIP_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (auto& ev : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

@@ -4,7 +4,7 @@
 #include <stddef.h>
 
 enum GemmMode { GEMM_DENSE = 0, GEMM_STRIDED = 1, GEMM_CONV3 = 2, GEMM_STEM = 3 };
-enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3 };
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3, TILE_128x128_W8 = 4, TILE_128x64_W8 = 5, TILE_256x128_W8 = 6 };
 
 // Arguments of the implicit-GEMM kernel (conv_gemm.hip).  All offsets are in floats.
 struct GemmArgs {

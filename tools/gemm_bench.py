@@ -40,7 +40,7 @@ for M, N, K, tile in cases:
     ms = e0.elapsed_time(e1) / n
     clk = ""
     if os.environ.get("HPE_CLK"):
-        bm0, bn0 = [(128, 128), (128, 64), (64, 64), (64, 128)][tile]
+        bm0, bn0 = [(128, 128), (128, 64), (64, 64), (64, 128), (128, 128), (128, 64), (256, 128)][tile]
         nw = ((M + bm0 - 1) // bm0) * ((N + bn0 - 1) // bn0)
         dbg = torch.zeros(2 * nw, dtype=torch.int64, device="cuda")
         _lib.check(eng.lib.hpe_debug_set_dbg(eng._h, dbg.data_ptr()))
@@ -53,6 +53,6 @@ for M, N, K, tile in cases:
         clk = " clk(GHz) med=%.3f min=%.3f max=%.3f loop_us=%.1f" % (np.median(ghz), ghz.min(), ghz.max(), np.median(d[:, 1]) / 100.0)
     ref = x[:256] @ w[:N].T
     err = float((y[:256] - ref).abs().max() / ref.abs().max())
-    bm, bn = [(128, 128), (128, 64), (64, 64), (64, 128)][tile]
+    bm, bn = [(128, 128), (128, 64), (64, 64), (64, 128), (128, 128), (128, 64), (256, 128)][tile]
     wgs = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     print("M=%6d N=%4d K=%5d tile=%dx%d wgs=%5d  %8.3f ms  %6.1f TF  err=%.1e%s" % (M, N, K, bm, bn, wgs, ms, 2.0 * M * N * K / ms / 1e9, err, clk))
