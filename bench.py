@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 ENCODER_GFLOP_PER_IMG = 7.711850496  # 2 * 3,855,925,248 MAC (resnet_spec.encoder_macs_per_image)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
 
 
 def main():
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE metric: 256)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="images of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16 = BASELINE configs[3] (bf16 encoder, fp32 SMPL)")
     ap.add_argument("--config5", action="store_true", help="also evaluate kp + mesh reprojection losses of every stage (BASELINE configs[4])")
     args = ap.parse_args()
 
@@ -75,6 +77,7 @@ def main():
     class Cfg(object):
         img_size, num_stage, batch_size, data_format = 224, 3, B, "NHWC"
         checkpoint_dir = smpl_model_path = None
+        encoder_dtype = args.encoder_dtype
 
     pred = hpe_amd.Predictor(Cfg(), smpl_model=smpl, mean_params=mean_vals, encoder_params=enc, regressor_params=reg,
                              device=local_rank)
@@ -145,20 +148,29 @@ def main():
         ts = eng.timings()
         per_conv = eng.conv_timings()
         serial_tf = ENCODER_GFLOP_PER_IMG * B / ts["conv_ms"]
+        PEAK = PEAK_FP32_MFMA_TFLOPS if args.encoder_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roofline = {
             "bound": "mfma",
-            "kernel": "conv_gemm_f32_kernel (53 launches/step, all tile instantiations; batch chunks on %s concurrent streams)"
-                      % os.environ.get("HPE_STREAMS", "3"),
+            "kernel": ("conv_gemm_f32_dma_kernel" if args.encoder_dtype == "fp32" else "conv_gemm_bf16_dma_kernel")
+                      + " (53 launches/step, all tile instantiations; batch chunks on %s concurrent streams)" % os.environ.get("HPE_STREAMS", "3"),
             "achieved": round(achieved, 3),
-            "peak": PEAK_FP32_MFMA_TFLOPS,
+            "peak": PEAK,
             "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac": round(achieved / PEAK, 4),
             "traffic": None,
             "launch_ms": round(span_ms, 4),
             "flop_per_launch": ENCODER_GFLOP_PER_IMG * B * 1e9,
             "serial": {"sum_of_53_launch_ms": round(ts["conv_ms"], 4), "achieved": round(serial_tf, 3),
-                       "frac": round(serial_tf / PEAK_FP32_MFMA_TFLOPS, 4)},
+                       "frac": round(serial_tf / PEAK, 4)},
         }
+        if args.encoder_dtype == "bf16":
+            # at 16x the fp32 matrix rate the bf16 encoder is HBM bound: price it in algorithmic bytes
+            nbytes = hpe_amd.resnet_spec.encoder_min_bytes_per_image(2) * B
+            gbs = nbytes / span_ms / 1e6
+            roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                             "bytes_per_launch": nbytes, "mfma_tflops": round(achieved, 1)})
+            roofline.pop("flop_per_launch")
+            roofline["serial"] = {"sum_of_53_launch_ms": round(ts["conv_ms"], 4)}
         phase = {"encoder_ms": round(tm["encoder_ms"], 3), "regress_smpl_ms": round(tm["regress_smpl_ms"], 3),
                  "step_ms_events": round(tm["total_ms"], 3)}
         eng.enable_timing(0)
@@ -208,7 +220,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.encoder_dtype == "fp32" else "bf16 (encoder; fp32 accumulate, fp32 regressor+SMPL)",
             "data": "synthetic",
             "config": {
                 "workload": "batch=%d/GPU 224x224x3 synthetic images, fp32 ResNet-50 v1 + 3-iter regressor + SMPL LBS at all 3 "

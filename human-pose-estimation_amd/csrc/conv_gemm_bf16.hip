@@ -1,0 +1,423 @@
+// conv_gemm_bf16.hip -- bf16 implicit-GEMM convolution on the gfx950 matrix cores (BASELINE config 4: bf16 encoder,
+// fp32 accumulate, fp32 regressor + SMPL).  Same structure as the fp32 LDS-DMA kernel of conv_gemm.hip:
+//   Y[m][n] = act((sum_k A[m][k] * Wt[n][k]) * scale[n] + shift[n] + R[m][n]),  A / Wt / R / Y in bf16, sum in fp32.
+// A k-slab is 64 bf16 = one 128-B line per row, so the byte geometry of the staging (8 x 16-B chunks per row, 1-KiB
+// global_load_lds_dwordx4 pieces, source-side XOR swizzle) is identical to the fp32 kernel; one ds_read_b128 per lane is
+// exactly one operand of v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8*(l>>5)..+7 of the 16-deep step).
+// At 16x the fp32 matrix rate the encoder is HBM / L2 bound in bf16: everything here is about moving 128-B lines.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hpe_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BKE 64  // bf16 elements per k-slab (128 B)
+#define RF 32   // floats per staged LDS row (128 B)
+
+namespace {
+
+struct RowB {
+    int base;  // element offset (bf16 elements) of this lane's 16-B chunk in slab 0
+    unsigned mask;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowB make_row_b(const GemmArgs& p, int m, int lc) {
+    RowB r;
+    r.mask = 0x1ffu;
+    if (m >= p.M) m = p.M - 1;
+    if (MODE == GEMM_DENSE) {
+        r.base = m * p.lda + lc * 8;
+    } else {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        if (MODE == GEMM_STRIDED) {
+            r.base = ((b * p.Hi + ho * p.stride) * p.Wi + wo * p.stride) * p.Cin + lc * 8;
+        } else if (MODE == GEMM_CONV3) {
+            r.base = ((b * p.Hi + ho) * p.Wi + wo) * p.Cin + lc * 8;
+            unsigned mk = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+                if ((unsigned)(ho + dh) < (unsigned)p.Hi && (unsigned)(wo + dw) < (unsigned)p.Wi) mk |= 1u << tap;
+            }
+            r.mask = mk;
+        } else {
+            // STEM: padded input [B,Hi,Wi,4] bf16; one slab = kernel rows (2s, 2s+1), each 8 px x 4 ch = 64 B
+            r.base = ((b * p.Hi + 2 * ho + (lc >> 2)) * p.Wi + 2 * wo) * 4 + (lc & 3) * 8;
+        }
+    }
+    return r;
+}
+
+struct SlabB {
+    int off, tap, cs;
+};
+
+template <int MODE>
+__device__ __forceinline__ void slab_advance_b(const GemmArgs& p, SlabB& sp) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
+        sp.off += BKE;
+    } else if (MODE == GEMM_CONV3) {
+        sp.cs += 1;
+        sp.off += BKE;
+        if (sp.cs == p.cin_slabs) {
+            sp.cs = 0;
+            sp.tap += 1;
+            const int kh = sp.tap / 3;
+            sp.off = ((kh - 1) * p.Wi + (sp.tap - kh * 3 - 1)) * p.Cin;
+        }
+    } else {
+        sp.off += 2 * p.Wi * 4;
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dma_kernel(GemmArgs p) {
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int NW = WM * WN;
+    constexpr int NTHR = 64 * NW;
+    constexpr int AP = BM / (8 * NW);
+    constexpr int BP = BN / (8 * NW);
+    constexpr int EP = BN + 4;
+    constexpr int BUF = (BM + BN) * RF;
+    constexpr int LDS_FLOATS = (2 * BUF > BM * EP) ? 2 * BUF : BM * EP;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(AP >= 1 && BP >= 1, "tile too small for the wave count");
+
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const __bf16* __restrict__ X = reinterpret_cast<const __bf16*>(p.x);
+    const __bf16* __restrict__ W = reinterpret_cast<const __bf16*>(p.w);
+    const __bf16* __restrict__ R = reinterpret_cast<const __bf16*>(p.res);
+    __bf16* __restrict__ Y = reinterpret_cast<__bf16*>(p.y);
+
+    const int total = p.n_mtiles * p.n_ntiles;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int mtile = swz / p.n_ntiles;
+    const int ntile = swz - mtile * p.n_ntiles;
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+
+    const int drow = lane >> 3;
+    RowB arow[AP];
+    const __bf16* wsrc[BP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int r = (NW * i + wave) * 8 + drow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        arow[i] = make_row_b<MODE>(p, m0 + r, lc);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int r = (NW * i + wave) * 8 + drow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[i] = W + (size_t)(n0 + r) * p.ldw + lc * 8;
+    }
+
+    int a_row[MT], b_row[NT], a_x[MT], b_x[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = (wm * MT + i) * 32 + (lane & 31);
+        a_row[i] = r * RF;
+        a_x[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = (wn * NT + j) * 32 + (lane & 31);
+        b_row[j] = (BM + r) * RF;
+        b_x[j] = (r >> 1) & 7;
+    }
+    const int hi = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int S = p.K / BKE;
+    SlabB sp;
+    sp.tap = 0;
+    sp.cs = 0;
+    sp.off = (MODE == GEMM_CONV3) ? (-p.Wi - 1) * p.Cin : 0;
+
+    auto issue_dma = [&](int slab, int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const void* src;
+            if (MODE == GEMM_CONV3) {
+                const bool ok = (arow[i].mask >> sp.tap) & 1u;
+                src = ok ? static_cast<const void*>(X + (arow[i].base + sp.off)) : static_cast<const void*>(p.zero);
+            } else {
+                src = X + (arow[i].base + sp.off);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (NW * i + wave) * 8 * RF), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + slab * BKE),
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (BM + (NW * i + wave) * 8) * RF), 16, 0,
+                                             0);
+        }
+    };
+
+    issue_dma(0, 0);
+    __syncthreads();
+
+    for (int s = 0; s < S; ++s) {
+        const int cur = (s & 1) * BUF;
+        if (s + 1 < S) {
+            slab_advance_b<MODE>(p, sp);
+            issue_dma(s + 1, BUF - cur);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x8 fa[MT], fb[NT];
+            const int lc = 2 * g + hi;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + a_row[i] + ((lc ^ a_x[i]) << 2)]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&lds[cur + b_row[j] + ((lc ^ b_x[j]) << 2)]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: fp32 scale/shift, transpose through LDS, rows leave as 16 B (8 bf16) per lane
+    {
+        const int col_l = lane & 31;
+        const int row_l = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cl = (wn * NT + j) * 32 + col_l;
+            const int n = n0 + cl;
+            const bool n_ok = n < p.N;
+            const float sc = n_ok ? p.scale[n] : 0.f;
+            const float sh = n_ok ? p.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rl = (wm * MT + i) * 32 + row_l;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) lds[(rl + (e & 3) + 8 * (e >> 2)) * EP + cl] = acc[i][j][e] * sc + sh;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int TPR = BN / 8;
+        constexpr int RPP = NTHR / TPR;
+        const int r = t / TPR;
+        const int c8 = (t - r * TPR) * 8;
+        const int n = n0 + c8;
+        const bool full = (n + 7) < p.N;
+#pragma unroll 4
+        for (int pass = 0; pass < BM / RPP; ++pass) {
+            const int row = pass * RPP + r;
+            const int m = m0 + row;
+            if (m >= p.M || n >= p.N) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&lds[row * EP + c8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&lds[row * EP + c8 + 4]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (full) {
+                if (R) {
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * p.ldres + n);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += (float)rv[u];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = (__bf16)(p.relu ? fmaxf(v[u], 0.f) : v[u]);
+                *reinterpret_cast<bf16x8*>(Y + (size_t)m * p.ldy + n) = o;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (n + u < p.N) {
+                        float o = v[u];
+                        if (R) o += (float)R[(size_t)m * p.ldres + n + u];
+                        if (p.relu) o = fmaxf(o, 0.f);
+                        Y[(size_t)m * p.ldy + n + u] = (__bf16)o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+hipError_t launch_cfg_b(GemmArgs& p, hipStream_t st) {
+    p.n_mtiles = (p.M + BM - 1) / BM;
+    p.n_ntiles = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_gemm_bf16_dma_kernel<MODE, BM, BN, WM, WN>), dim3(p.n_mtiles * p.n_ntiles), dim3(64 * WM * WN), 0, st, p);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_mode_b(GemmArgs& p, int tile, hipStream_t st) {
+    switch (tile) {
+        case TILE_128x128: return launch_cfg_b<MODE, 128, 128, 2, 2>(p, st);
+        case TILE_128x64: return launch_cfg_b<MODE, 128, 64, 2, 2>(p, st);
+        case TILE_64x64: return launch_cfg_b<MODE, 64, 64, 2, 2>(p, st);
+        case TILE_64x128: return launch_cfg_b<MODE, 64, 128, 2, 2>(p, st);
+        case TILE_128x128_W8: return launch_cfg_b<MODE, 128, 128, 2, 4>(p, st);
+        case TILE_128x64_W8: return launch_cfg_b<MODE, 128, 64, 4, 2>(p, st);
+        case TILE_256x128_W8: return launch_cfg_b<MODE, 256, 128, 4, 2>(p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- glue ops in bf16
+// img [B,H,W,3] fp32 -> out [B,Hp,Wp,4] bf16 (zero border, 4th channel 0); 8 B per thread
+__global__ void pad_input_bf16_kernel(const float* __restrict__ img, uint2* __restrict__ out, int B, int H, int W, int Hp, int Wp) {
+    const long total = (long)B * Hp * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const long r = i / Wp;
+        const int yp = (int)(r % Hp);
+        const int b = (int)(r / Hp);
+        const int x = xp - 3, y = yp - 3;
+        __bf16 v[4] = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const float* s = img + (((long)b * H + y) * W + x) * 3;
+            v[0] = (__bf16)s[0];
+            v[1] = (__bf16)s[1];
+            v[2] = (__bf16)s[2];
+        }
+        uint2 o;
+        __builtin_memcpy(&o, v, 8);
+        out[i] = o;
+    }
+}
+
+__global__ void maxpool3x3s2_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, int B, int H, int C8) {
+    const int Ho = H / 2;
+    const long total = (long)B * Ho * Ho * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long r = i / C8;
+        const int wo = (int)(r % Ho);
+        r /= Ho;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = 0.f;  // zero padding takes part in the max; inputs are post-ReLU (>= 0)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * ho - 1 + dy;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * wo - 1 + dx;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)H) {
+                    const bf16x8 v = x[(((long)b * H + yy) * H + xx) * C8 + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) m[u] = fmaxf(m[u], (float)v[u]);
+                }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = (__bf16)m[u];
+        y[i] = o;
+    }
+}
+
+__global__ void avgpool_bf16_kernel(const bf16x8* __restrict__ x, float* __restrict__ y, int B, int HW, int C8, int ldy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C8) return;
+    const int c = i % C8;
+    const int b = i / C8;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    const bf16x8* p = x + (long)b * HW * C8 + c;
+    for (int k = 0; k < HW; ++k) {
+        const bf16x8 v = p[(long)k * C8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += (float)v[u];
+    }
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y[(long)b * ldy + c * 8 + u] = s[u] * inv;
+}
+
+inline int grid_for(long total, int block, int cap = 2048) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BKE) != 0 || (p.ldw % 8) != 0 || p.ldw < p.K) return hipErrorInvalidValue;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift || !p.zero) return hipErrorInvalidValue;
+    if ((p.ldy % 8) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
+    if (p.res && ((p.ldres % 8) != 0 || ((uintptr_t)p.res & 15) != 0)) return hipErrorInvalidValue;
+    if (((uintptr_t)p.x & 15) != 0 || ((uintptr_t)p.w & 15) != 0) return hipErrorInvalidValue;
+    const int bn = (tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x128_W8 || tile == TILE_256x128_W8) ? 128 : 64;
+    if (((p.N + bn - 1) / bn) * bn > p.w_rows) return hipErrorInvalidValue;
+    switch (mode) {
+        case GEMM_DENSE:
+            if (p.lda < p.K || (p.lda % 8) != 0) return hipErrorInvalidValue;
+            return launch_mode_b<GEMM_DENSE>(p, tile, st);
+        case GEMM_STRIDED:
+            if (p.Cin != p.K || (p.Cin % 8) != 0) return hipErrorInvalidValue;
+            if ((p.Ho - 1) * p.stride >= p.Hi || (p.Wo - 1) * p.stride >= p.Wi) return hipErrorInvalidValue;
+            return launch_mode_b<GEMM_STRIDED>(p, tile, st);
+        case GEMM_CONV3:
+            if ((p.Cin % BKE) != 0 || p.K != 9 * p.Cin || p.cin_slabs != p.Cin / BKE || p.Ho != p.Hi || p.Wo != p.Wi)
+                return hipErrorInvalidValue;
+            return launch_mode_b<GEMM_CONV3>(p, tile, st);
+        case GEMM_STEM:
+            if (p.K != 4 * BKE || p.Hi < 2 * (p.Ho - 1) + 8 || p.Wi < 2 * (p.Wo - 1) + 8) return hipErrorInvalidValue;
+            return launch_mode_b<GEMM_STEM>(p, tile, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st) {
+    const long total = (long)B * Hp * Wp;
+    hipLaunchKernelGGL(pad_input_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, img, reinterpret_cast<uint2*>(out), B, H, W,
+                       Hp, Wp);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_maxpool_bf16(const void* x, void* y, int B, int H, int C, hipStream_t st) {
+    if ((C % 8) != 0 || (H % 2) != 0) return hipErrorInvalidValue;
+    const long total = (long)B * (H / 2) * (H / 2) * (C / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const bf16x8*>(x),
+                       reinterpret_cast<bf16x8*>(y), B, H, C / 8);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, int ldy, hipStream_t st) {
+    if ((C % 8) != 0) return hipErrorInvalidValue;
+    const int total = B * (C / 8);
+    hipLaunchKernelGGL(avgpool_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const bf16x8*>(x), y, B, HW,
+                       C / 8, ldy);
+    return hipGetLastError();
+}

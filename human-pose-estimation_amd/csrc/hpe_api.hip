@@ -83,11 +83,17 @@ inline int round_up(int x, int m) { return ((x + m - 1) / m) * m; }
 struct ConvLayer {
     std::vector<float> kernel, bias, gamma, beta, mean, var;  // host staging (Keras layouts)
     bool loaded = false;
-    float* w = nullptr;  // device, packed [n_pad][k_pad]
+    float* w = nullptr;  // device, packed [n_pad][k_pad] (fp32) or bf16 [n_pad][k_pad16] in bf16 mode
     float* scale = nullptr;
     float* shift = nullptr;
     int n_pad = 0, k_pad = 0;
 };
+
+inline unsigned short f2bf(float f) {  // round-to-nearest-even fp32 -> bf16 (finite inputs)
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
 
 struct DenseLayer {
     std::vector<float> kernel, bias;
@@ -103,6 +109,7 @@ constexpr int THETA_LD = 96;  // theta rows padded to 3 k-slabs of 32
 struct hpe_ctx {
     HpeConfig cfg{};
     bool finalized = false;
+    bool bf16 = false;  // encoder_dtype == 1
     bool have_encoder = false, have_regressor = false, have_smpl = false;
     ConvLayer conv[HPE_NUM_CONV];
     DenseLayer dense[HPE_NUM_DENSE];
@@ -188,6 +195,18 @@ int pick_tile(int M, int N) {
     return TILE_64x64;
 }
 
+int pick_tile_bf16(int M, int N) {
+    static int force = -2;
+    if (force == -2) {
+        const char* e = getenv("HPE_TILE_BF16");
+        force = e ? atoi(e) : -1;
+    }
+    if (N <= 64) return TILE_128x64;
+    if (force >= 0) return force;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return t128 >= 512 ? TILE_128x128 : TILE_64x128;
+}
+
 #define HIPE(expr)                               \
     do {                                         \
         hipError_t _e = (expr);                  \
@@ -233,6 +252,10 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     } else {
         mode = GEMM_STRIDED;
     }
+    if (c->bf16) {
+        p.cin_slabs = s.cin / 64;
+        return hpe_launch_gemm_bf16(p, mode, pick_tile_bf16(p.M, p.N), st);
+    }
     return hpe_launch_gemm(p, mode, pick_tile(p.M, p.N), st);
 }
 
@@ -268,19 +291,28 @@ hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* r
 
 // the encoder on images [i0, i0+B) of the batch (all workspace buffers are image-major)
 hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* features, int ldfeat, hipStream_t st) {
+    // all workspace buffers are image-major; in bf16 mode the same allocations hold bf16 elements (half the bytes)
+    const int esz = c->bf16 ? 2 : 4;
+    auto at = [&](float* base, size_t elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elems * esz); };
     const size_t o_img = (size_t)i0 * HPE_IMG_SIZE * HPE_IMG_SIZE * 3;
     const size_t o_pad = (size_t)i0 * STEM_HP * STEM_WP * 4;
     const size_t o_big = (size_t)i0 * 802816;
     const size_t o_mid = (size_t)i0 * 200704;
-    float* padded = c->padded + o_pad;
-    float* SC = c->SC + o_big;
-    float* T1 = c->T1 + o_mid;
-    float* T2 = c->T2 + o_mid;
-    HIPE(hpe_launch_pad_input(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
-    HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
-    HIPE(hpe_launch_maxpool(SC, c->X0 + o_big, B, 112, 64, st));
-    float* cur = c->X0 + o_big;
-    float* nxt = c->X1 + o_big;
+    float* padded = at(c->padded, o_pad);
+    float* SC = at(c->SC, o_big);
+    float* T1 = at(c->T1, o_mid);
+    float* T2 = at(c->T2, o_mid);
+    float* cur = at(c->X0, o_big);
+    float* nxt = at(c->X1, o_big);
+    if (c->bf16) {
+        HIPE(hpe_launch_pad_input_bf16(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
+        HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
+        HIPE(hpe_launch_maxpool_bf16(SC, cur, B, 112, 64, st));
+    } else {
+        HIPE(hpe_launch_pad_input(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
+        HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
+        HIPE(hpe_launch_maxpool(SC, cur, B, 112, 64, st));
+    }
     int ci = 1;
     const int nblk[4] = {3, 4, 6, 3};
     for (int stg = 0; stg < 4; ++stg) {
@@ -302,6 +334,7 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
             nxt = t;
         }
     }
+    if (c->bf16) return hpe_launch_avgpool_bf16(cur, features + (size_t)i0 * ldfeat, B, 49, HPE_FEATURE_DIM, ldfeat, st);
     return hpe_launch_avgpool(cur, features + (size_t)i0 * ldfeat, B, 49, HPE_FEATURE_DIM, ldfeat, st);
 }
 
@@ -385,7 +418,7 @@ int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
     if (!cfg || !out) return fail(HPE_ERR_INVALID, "null argument");
     if (cfg->max_batch < 1 || cfg->max_batch > 1024) return fail(HPE_ERR_INVALID, "max_batch must be in [1,1024]");
     if (cfg->num_stage < 1 || cfg->num_stage > 16) return fail(HPE_ERR_INVALID, "num_stage must be in [1,16]");
-    if (cfg->encoder_dtype != 0) return fail(HPE_ERR_INVALID, "encoder_dtype: only 0 (fp32) is implemented");
+    if (cfg->encoder_dtype != 0 && cfg->encoder_dtype != 1) return fail(HPE_ERR_INVALID, "encoder_dtype must be 0 (fp32) or 1 (bf16)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(HPE_ERR_NO_DEVICE, "no HIP device visible");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(HPE_ERR_INVALID, "device ordinal out of range");
@@ -395,6 +428,7 @@ int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
         return fail(HPE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     hpe_ctx* c = new hpe_ctx();
     c->cfg = *cfg;
+    c->bf16 = cfg->encoder_dtype == 1;
     if (c->cfg.bn_eps <= 0.f) c->cfg.bn_eps = 1e-3f;
     *out = c;
     return HPE_OK;
@@ -500,6 +534,23 @@ int hpe_finalize(hpe_ctx* c) {
         const ConvSpec& s = specs()[i];
         ConvLayer& L = c->conv[i];
         L.n_pad = round_up(s.cout, 128);
+        if (c->bf16) {
+            // bf16: 64-element slabs; stem slab s = kernel rows (2s, 2s+1), each 8 px x 4 ch
+            L.k_pad = (i == 0) ? 4 * 64 : round_up(s.kh * s.kw * s.cin, 64);
+            std::vector<unsigned short> wt((size_t)L.n_pad * L.k_pad, 0);
+            for (int kh = 0; kh < s.kh; ++kh)
+                for (int kw = 0; kw < s.kw; ++kw)
+                    for (int ci = 0; ci < s.cin; ++ci) {
+                        const int k = (i == 0) ? (kh * 32 + kw * 4 + ci) : ((kh * s.kw + kw) * s.cin + ci);
+                        const float* src = &L.kernel[(((size_t)kh * s.kw + kw) * s.cin + ci) * s.cout];
+                        for (int n = 0; n < s.cout; ++n) wt[(size_t)n * L.k_pad + k] = f2bf(src[n]);
+                    }
+            void* q = nullptr;
+            HIP_TRY(hipMalloc(&q, wt.size() * 2));
+            c->allocs.push_back(q);
+            HIP_TRY(hipMemcpy(q, wt.data(), wt.size() * 2, hipMemcpyHostToDevice));
+            L.w = static_cast<float*>(q);
+        } else {
         L.k_pad = (i == 0) ? 7 * 32 : round_up(s.kh * s.kw * s.cin, 32);
         std::vector<float> wt((size_t)L.n_pad * L.k_pad, 0.f);
         for (int kh = 0; kh < s.kh; ++kh)
@@ -509,13 +560,14 @@ int hpe_finalize(hpe_ctx* c) {
                     const float* src = &L.kernel[(((size_t)kh * s.kw + kw) * s.cin + ci) * s.cout];
                     for (int n = 0; n < s.cout; ++n) wt[(size_t)n * L.k_pad + k] = src[n];
                 }
+        if ((rc = upload(c, &L.w, wt))) return rc;
+        }
         std::vector<float> sc(s.cout), sh(s.cout);
         for (int n = 0; n < s.cout; ++n) {
             const double inv = (double)L.gamma[n] / std::sqrt((double)L.var[n] + (double)c->cfg.bn_eps);
             sc[n] = (float)inv;
             sh[n] = (float)(((double)L.bias[n] - (double)L.mean[n]) * inv + (double)L.beta[n]);
         }
-        if ((rc = upload(c, &L.w, wt))) return rc;
         if ((rc = upload(c, &L.scale, sc))) return rc;
         if ((rc = upload(c, &L.shift, sh))) return rc;
         std::vector<float>().swap(L.kernel);
@@ -762,6 +814,7 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
     int rc = check_ready(c, B, NEED_ENC);
     if (rc) return rc;
     if (idx < 0 || idx >= HPE_NUM_CONV || !x || !y) return fail(HPE_ERR_INVALID, "bad argument");
+    if (c->bf16) return fail(HPE_ERR_STATE, "hpe_debug_conv works on fp32 contexts only");
     DeviceGuard g(c->cfg.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float* in = x;

@@ -25,6 +25,12 @@ struct GemmArgs {
 
 hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st);
 
+// conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
+hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st);
+hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
+hipError_t hpe_launch_maxpool_bf16(const void* x, void* y, int B, int H, int C, hipStream_t st);
+hipError_t hpe_launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, int ldy, hipStream_t st);
+
 // encoder_ops.hip
 hipError_t hpe_launch_pad_input(const float* img, float* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
 hipError_t hpe_launch_maxpool(const float* x, float* y, int B, int H, int C, hipStream_t st);

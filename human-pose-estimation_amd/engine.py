@@ -34,7 +34,7 @@ def _require_cuda_tensor(t, name, shape_tail=None):
 
 
 class HpeEngine(object):
-    def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3):
+    def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3, encoder_dtype="fp32"):
         self.lib = _lib.load()
         torch = _torch()
         if not torch.cuda.is_available():
@@ -43,7 +43,10 @@ class HpeEngine(object):
         self.max_batch = int(max_batch)
         self.num_stage = int(num_stage)
         self.num_kp = 19
-        cfg = _lib.HpeConfig(self.device, self.max_batch, self.num_stage, float(bn_eps), 0)
+        if encoder_dtype not in ("fp32", "bf16"):
+            raise ValueError("encoder_dtype must be 'fp32' or 'bf16'")
+        self.encoder_dtype = encoder_dtype
+        cfg = _lib.HpeConfig(self.device, self.max_batch, self.num_stage, float(bn_eps), 1 if encoder_dtype == "bf16" else 0)
         h = C.c_void_p()
         _lib.check(self.lib.hpe_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -83,7 +83,8 @@ class Predictor(object):
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self.engine = _engine.HpeEngine(
-            device=device, max_batch=self.batch_size, num_stage=self.num_stage, bn_eps=getattr(config, "bn_eps", 1e-3)
+            device=device, max_batch=self.batch_size, num_stage=self.num_stage, bn_eps=getattr(config, "bn_eps", 1e-3),
+            encoder_dtype=getattr(config, "encoder_dtype", "fp32"),
         )
         # ---- SMPL (reference :55)
         if smpl_model is None:

@@ -53,3 +53,23 @@ def encoder_param_count():
 
 def encoder_macs_per_image():
     return sum(s.kh * s.kw * s.cin * s.cout * s.hout * s.hout for s in CONV_SPECS)
+
+
+def encoder_min_bytes_per_image(elem_bytes=4):
+    """Algorithmic HBM bytes of the encoder per image when every activation tensor is written once and read once
+    by each consumer (no on-chip fusion across layers): conv inputs actually touched (1x1/s2 convs read one pixel
+    in four), conv outputs, residual reads of the 2c layers, the two pools; plus the fp32 input image and its padded
+    copy.  Weights (read once per batch) are not included."""
+    total = 224 * 224 * 3 * 4  # fp32 image read by the pad kernel
+    total += 2 * 230 * 232 * 4 * elem_bytes  # padded copy written + read by conv1
+    for s in CONV_SPECS:
+        if s.name == "conv1":
+            total += s.hout * s.hout * s.cout * elem_bytes  # conv1 out
+            total += s.hout * s.hout * s.cout * elem_bytes + 56 * 56 * 64 * elem_bytes  # max-pool read + write
+            continue
+        total += s.hout * s.hout * s.cin * elem_bytes * (9 if False else 1)  # input pixels touched (taps hit L2)
+        total += s.hout * s.hout * s.cout * elem_bytes  # output
+        if s.name.endswith("2c"):
+            total += s.hout * s.hout * s.cout * elem_bytes  # residual
+    total += 7 * 7 * 2048 * elem_bytes + 2048 * 4  # avg-pool
+    return total

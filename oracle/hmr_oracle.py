@@ -246,7 +246,7 @@ def _t(x, dtype):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
 
 
-def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False):
+def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False, act_round=None):
     """reference: src/models.py:35-41 -> keras.applications.ResNet50(include_top=False, pooling='avg')
     (keras_applications 1.0.8 resnet50.py; BN epsilon 1e-3 there, 1.001e-5 in tf.keras>=2.2 resnet.py --
     hence the parameter).  images [B,224,224,3] NHWC in [-1,1] -> features [B,2048].
@@ -259,9 +259,13 @@ def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False):
 
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     taps = {}
+    # act_round="bf16": emulation of the bf16 encoder variant (BASELINE config 4) -- the input, the conv kernels and
+    # every stored activation (after BN / residual add / ReLU) are rounded to bfloat16 (RNE); accumulation, BN
+    # scale/shift and the pools stay in `dtype`.  Not a reference behaviour: a checker for the bf16 HIP path.
+    rnd = (lambda v: v.to(torch.bfloat16).to(tdt)) if act_round == "bf16" else (lambda v: v)
 
     def conv(x, name, stride=1, padding=0):
-        w = _t(p[name + "/kernel"], tdt).permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
+        w = rnd(_t(p[name + "/kernel"], tdt)).permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
         return F.conv2d(x, w, _t(p[name + "/bias"], tdt), stride=stride, padding=padding)
 
     def bn(x, name):
@@ -272,9 +276,9 @@ def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False):
         return (x - m) * torch.rsqrt(v + eps) * g + b
 
     with torch.no_grad():
-        x = _t(images, tdt).permute(0, 3, 1, 2)
+        x = rnd(_t(images, tdt)).permute(0, 3, 1, 2)
         x = F.pad(x, (3, 3, 3, 3))
-        x = torch.relu(bn(conv(x, "conv1", stride=2), "bn_conv1"))
+        x = rnd(torch.relu(bn(conv(x, "conv1", stride=2), "bn_conv1")))
         taps["conv1"] = x
         x = F.pad(x, (1, 1, 1, 1))
         x = F.max_pool2d(x, 3, stride=2)
@@ -285,11 +289,11 @@ def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False):
                 cn = "res%d%s_branch" % (stage, blk)
                 bnn = "bn%d%s_branch" % (stage, blk)
                 s = 2 if (b == 0 and stage > 2) else 1
-                y = torch.relu(bn(conv(x, cn + "2a", stride=s), bnn + "2a"))
-                y = torch.relu(bn(conv(y, cn + "2b", padding=1), bnn + "2b"))
+                y = rnd(torch.relu(bn(conv(x, cn + "2a", stride=s), bnn + "2a")))
+                y = rnd(torch.relu(bn(conv(y, cn + "2b", padding=1), bnn + "2b")))
                 y = bn(conv(y, cn + "2c"), bnn + "2c")
-                sc = bn(conv(x, cn + "1", stride=s), bnn + "1") if b == 0 else x
-                x = torch.relu(y + sc)
+                sc = rnd(bn(conv(x, cn + "1", stride=s), bnn + "1")) if b == 0 else x
+                x = rnd(torch.relu(y + sc))
                 taps["res%d%s" % (stage, blk)] = x
         feat = x.mean(dim=(2, 3))
     out = feat.numpy().astype(dtype)

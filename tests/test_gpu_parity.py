@@ -281,6 +281,37 @@ def test_val_step_losses_match_oracle(assets):
     assert tuple(r["pred_keypoints"].shape) == (3, 3, 19, 2) and tuple(r["generated_verts"].shape) == (3, 3, 6890, 3)
 
 
+# ------------------------------------------------------------------------------------------- bf16 encoder (config 4)
+def test_bf16_encoder_variant(assets):
+    """BASELINE config 4: bf16 encoder (bf16 MFMA, fp32 accumulate) + fp32 regressor / SMPL.  Parity is REPORTED against
+    the fp32 oracle and checked against a bf16-rounding emulation of the oracle (same rounding points), not gated at 1e-4."""
+    eng = hpe_amd.HpeEngine(device=0, max_batch=4, encoder_dtype="bf16")
+    eng.load_smpl(assets["smpl"])
+    eng.load_encoder(assets["enc"])
+    eng.load_regressor(assets["reg"])
+    eng.load_mean_theta(assets["mean_var"])
+    eng.finalize()
+    img = synthetic.make_images(3, seed=61)
+    f = cpu(eng.encoder(gpu(img))).astype(np.float64)
+    emu = O.resnet50_features(img, assets["enc"], act_round="bf16").astype(np.float64)
+    f32 = O.resnet50_features(img, assets["enc"]).astype(np.float64)
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print("bf16 encoder: rel-L2 vs bf16-emulating oracle %.3g, vs fp32 oracle %.3g (emulation vs fp32 %.3g)" % (l2(f, emu), l2(f, f32), l2(emu, f32)))
+    assert l2(f, emu) < 1e-2
+    assert l2(f, f32) < 3e-2
+    out = eng.forward(gpu(img))[0]
+    ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"])
+    mpjpe = float(np.linalg.norm(cpu(out["joints"]) - ref["generated_joints"], axis=-1).mean())
+    print("bf16 encoder: MPJPE vs fp32 oracle %.3g (units of the SMPL template, ~metres)" % mpjpe)
+    assert mpjpe < 2e-2
+    # fp32 stages downstream of the features are exact given the features
+    th = cpu(eng.regress_stage(gpu(f.astype(np.float32))))
+    th_ref = np.tile(assets["mean_var"], (3, 1)) + O.regression_network(
+        np.concatenate([f.astype(np.float32), np.tile(assets["mean_var"], (3, 1))], 1), assets["reg"])
+    assert rel(th, th_ref) < 1e-5
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
 def test_full_size_batch_invariance_and_linearity(assets):
     """BASELINE full size (256 images / GPU): the oracle is too slow there, so check size-independent properties:
