@@ -67,7 +67,7 @@ def encoder_min_bytes_per_image(elem_bytes=4):
             total += s.hout * s.hout * s.cout * elem_bytes  # conv1 out
             total += s.hout * s.hout * s.cout * elem_bytes + 56 * 56 * 64 * elem_bytes  # max-pool read + write
             continue
-        total += s.hout * s.hout * s.cin * elem_bytes * (9 if False else 1)  # input pixels touched (taps hit L2)
+        total += s.hout * s.hout * s.cin * elem_bytes  # input pixels touched once (3x3 taps re-read from L2)
         total += s.hout * s.hout * s.cout * elem_bytes  # output
         if s.name.endswith("2c"):
             total += s.hout * s.hout * s.cout * elem_bytes  # residual
