@@ -3,8 +3,8 @@
 // bidirectional_dist -> find_nearest_neighbors (src/ops.py:60-137).
 //
 // The reference materialises a [P_i, 6890] fp32 distance matrix per image in a Python loop.  Here the
-// nearest-neighbour search is a tiled brute force: one point per lane with a running (min, argmin) in
-// registers, the other point set streamed through LDS (broadcast reads), no distance matrix in memory.
+// nearest-neighbour search is a tiled brute force: four points per lane with running (min, argmin) in
+// registers, the other point set streamed through LDS (broadcast ds_read_b128), no distance matrix in memory.
 // The squared distance is evaluated in the reference's expanded form ((-2 a.b) + |a|^2) + |b|^2 in fp32 and
 // ties keep the lowest index (tf.argmin), so the chosen neighbours follow the reference's choice.
 #include <hip/hip_runtime.h>
@@ -76,78 +76,123 @@ __global__ __launch_bounds__(256) void sil_compact_kernel(const float* __restric
 }
 
 // direction A -> B: every silhouette point a finds its nearest mesh vertex, contributes |a - b*|_1.
-// grid (ceil(HW/256), B); B's P points live in dynamic LDS.
+// grid (ceil(HW/1024), B); 4 points per lane (register tile), B's P points live in dynamic LDS as (x, y, |b|^2, 0)
+// so one broadcast ds_read_b128 serves 4 pair evaluations.
+#define NN_PT 4
+#define NN_BT 1024  // mesh vertices staged per LDS tile (16 KB) -- small enough for 8 waves/SIMD
 __global__ __launch_bounds__(256) void nn_a2b_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
                                                      const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
                                                      int nblk) {
-    extern __shared__ __attribute__((aligned(16))) float sB[];  // [P][2]
+    __shared__ __attribute__((aligned(16))) float sB[NN_BT * 4];  // (x, y, |b|^2, 0)
     __shared__ float red[4];
     const int b = blockIdx.y;
     const int cnt = counts[b];
-    const int base = blockIdx.x * 256;
+    const int base = blockIdx.x * 256 * NN_PT;
     if (base >= cnt) {
         if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = 0.f;
         return;
     }
     const float* Bp = v2d + (size_t)b * P * 2;
-    for (int i = threadIdx.x; i < 2 * P; i += 256) sB[i] = Bp[i];
-    __syncthreads();
-    const int idx = base + threadIdx.x;
-    float contrib = 0.f;
-    if (idx < cnt) {
-        const float ax = pts[((size_t)b * HW + idx) * 2], ay = pts[((size_t)b * HW + idx) * 2 + 1];
-        const float aa = ax * ax + ay * ay;
-        float best = 3.4e38f;
-        int bi = 0;
-        for (int p = 0; p < P; ++p) {
-            const float bx = sB[2 * p], by = sB[2 * p + 1];
-            const float d = (-2.0f * (ax * bx + ay * by) + aa) + (bx * bx + by * by);
-            if (d < best) {
-                best = d;
-                bi = p;
+    float ax[NN_PT], ay[NN_PT], aa[NN_PT], best[NN_PT], cx[NN_PT], cy[NN_PT];
+#pragma unroll
+    for (int u = 0; u < NN_PT; ++u) {
+        const int idx = min(base + u * 256 + (int)threadIdx.x, cnt - 1);
+        ax[u] = pts[((size_t)b * HW + idx) * 2];
+        ay[u] = pts[((size_t)b * HW + idx) * 2 + 1];
+        aa[u] = ax[u] * ax[u] + ay[u] * ay[u];
+        best[u] = 3.4e38f;
+        cx[u] = cy[u] = 0.f;
+    }
+    for (int p0 = 0; p0 < P; p0 += NN_BT) {
+        const int n = min(NN_BT, P - p0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float bx = Bp[2 * (p0 + i)], by = Bp[2 * (p0 + i) + 1];
+            *reinterpret_cast<float4*>(&sB[4 * i]) = make_float4(bx, by, bx * bx + by * by, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int p = 0; p < n; ++p) {
+            const float4 q = *reinterpret_cast<const float4*>(&sB[4 * p]);
+#pragma unroll
+            for (int u = 0; u < NN_PT; ++u) {
+                const float d = (-2.0f * (ax[u] * q.x + ay[u] * q.y) + aa[u]) + q.z;
+                const bool lt = d < best[u];  // strict: the lowest index keeps a tie (tf.argmin)
+                best[u] = lt ? d : best[u];
+                cx[u] = lt ? q.x : cx[u];
+                cy[u] = lt ? q.y : cy[u];
             }
         }
-        contrib = fabsf(ax - sB[2 * bi]) + fabsf(ay - sB[2 * bi + 1]);
+    }
+    float contrib = 0.f;
+#pragma unroll
+    for (int u = 0; u < NN_PT; ++u) {
+        const int idx = base + u * 256 + (int)threadIdx.x;
+        if (idx < cnt) contrib += fabsf(ax[u] - cx[u]) + fabsf(ay[u] - cy[u]);
     }
     const float s = block_sum_256(contrib, red);
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = s;
 }
 
 // direction B -> A: every mesh vertex finds its nearest silhouette point, contributes ||b - a*||_2.
-// grid (ceil(P/256), B); A streamed through LDS in tiles of 2048 points.
+// grid (ceil(P/1024), B); 4 vertices per lane; A streamed through LDS in tiles of 2048 points (x, y interleaved,
+// one broadcast ds_read_b128 = 2 points = 8 pair evaluations).
 __global__ __launch_bounds__(256) void nn_b2a_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
                                                      const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
                                                      int nblk, int blk_off) {
-    __shared__ __attribute__((aligned(16))) float sA[2048 * 2];
+    __shared__ __attribute__((aligned(16))) float sA[2048 * 2 + 4];
     __shared__ float red[4];
     const int b = blockIdx.y;
     const int cnt = counts[b];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const bool live = p < P;
-    const float bx = live ? v2d[((size_t)b * P + p) * 2] : 0.f;
-    const float by = live ? v2d[((size_t)b * P + p) * 2 + 1] : 0.f;
-    const float bb = bx * bx + by * by;
-    float best = 3.4e38f, cx = 0.f, cy = 0.f;
+    float bx[NN_PT], by[NN_PT], bb[NN_PT], best[NN_PT], cx[NN_PT], cy[NN_PT];
+    bool live[NN_PT];
+#pragma unroll
+    for (int u = 0; u < NN_PT; ++u) {
+        const int p = blockIdx.x * 256 * NN_PT + u * 256 + threadIdx.x;
+        live[u] = p < P;
+        const int pc = live[u] ? p : P - 1;
+        bx[u] = v2d[((size_t)b * P + pc) * 2];
+        by[u] = v2d[((size_t)b * P + pc) * 2 + 1];
+        bb[u] = bx[u] * bx[u] + by[u] * by[u];
+        best[u] = 3.4e38f;
+        cx[u] = cy[u] = 0.f;
+    }
     const float* Ap = pts + (size_t)b * HW * 2;
     for (int t0 = 0; t0 < cnt; t0 += 2048) {
         const int n = min(2048, cnt - t0);
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * n; i += 256) sA[i] = Ap[2 * t0 + i];
+        if ((n & 1) && threadIdx.x == 0) {  // pad to an even count with a copy of the last point (never wins a tie: later index)
+            sA[2 * n] = Ap[2 * (t0 + n - 1)];
+            sA[2 * n + 1] = Ap[2 * (t0 + n - 1) + 1];
+        }
         __syncthreads();
-        for (int i = 0; i < n; ++i) {
-            const float ax = sA[2 * i], ay = sA[2 * i + 1];
-            const float d = (-2.0f * (ax * bx + ay * by) + (ax * ax + ay * ay)) + bb;
-            if (d < best) {
-                best = d;
-                cx = ax;
-                cy = ay;
+        const int n2 = (n + 1) >> 1;
+        for (int i = 0; i < n2; ++i) {
+            const float4 q = *reinterpret_cast<const float4*>(&sA[4 * i]);
+            const float a0 = q.x * q.x + q.y * q.y, a1 = q.z * q.z + q.w * q.w;
+#pragma unroll
+            for (int u = 0; u < NN_PT; ++u) {
+                const float d0 = (-2.0f * (q.x * bx[u] + q.y * by[u]) + a0) + bb[u];
+                bool lt = d0 < best[u];
+                best[u] = lt ? d0 : best[u];
+                cx[u] = lt ? q.x : cx[u];
+                cy[u] = lt ? q.y : cy[u];
+                const float d1 = (-2.0f * (q.z * bx[u] + q.w * by[u]) + a1) + bb[u];
+                lt = d1 < best[u];
+                best[u] = lt ? d1 : best[u];
+                cx[u] = lt ? q.z : cx[u];
+                cy[u] = lt ? q.w : cy[u];
             }
         }
     }
     float contrib = 0.f;
-    if (live && cnt > 0) {
-        const float dx = bx - cx, dy = by - cy;
-        contrib = sqrtf(dx * dx + dy * dy);
+#pragma unroll
+    for (int u = 0; u < NN_PT; ++u) {
+        if (live[u] && cnt > 0) {
+            const float dx = bx[u] - cx[u], dy = by[u] - cy[u];
+            contrib += sqrtf(dx * dx + dy * dy);
+        }
     }
     const float s = block_sum_256(contrib, red);
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blk_off + blockIdx.x] = s;
@@ -176,30 +221,22 @@ hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* 
 
 size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P) {
     const int HW = H * W;
-    const int nblk = (HW + 255) / 256 + (P + 255) / 256;
+    const int nblk = (HW + 1023) / 1024 + (P + 1023) / 1024;
     return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64;
 }
 
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
                                 hipStream_t st) {
     const int HW = H * W;
-    const int nA = (HW + 255) / 256, nB = (P + 255) / 256;
+    const int nA = (HW + 1023) / 1024, nB = (P + 1023) / 1024;
     const int nblk = nA + nB;
-    if ((size_t)P * 2 * sizeof(float) > 150 * 1024) return hipErrorInvalidValue;  // B set must fit LDS
     float* pts = ws;
     float* partial = pts + (size_t)B * HW * 2;
     int* counts = reinterpret_cast<int*>(partial + (size_t)B * nblk);
     hipLaunchKernelGGL(sil_compact_kernel, dim3(B), dim3(256), 0, st, seg, HW, W, pts, counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t shm = (size_t)P * 2 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && shm > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(nn_a2b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), shm, st, pts, counts, v2d, HW, P, partial, nblk);
+    hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nn_b2a_kernel, dim3(nB, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk, nA);
