@@ -787,6 +787,53 @@ int hpe_reproject_vertices(const float* verts, const float* cam, int B, int P, f
     return HPE_OK;
 }
 
+int hpe_preprocess_u8(const unsigned char* img, int H, int W, int C, float* out224, int proc_param[5], void* stream) {
+    if (!img || !out224 || !proc_param || H < 1 || W < 1 || (C != 3 && C != 4)) return fail(HPE_ERR_INVALID, "bad argument");
+    const int S = HPE_IMG_SIZE;
+    const int mx = H > W ? H : W;
+    // preview.py:22-29 / image.py:7-15,17-39 -- all index arithmetic in double like numpy
+    const double scale = (mx != S) ? ((double)S / (double)mx) : 1.0;
+    const int newH = (int)std::floor(H * scale), newW = (int)std::floor(W * scale);
+    if (newH < 1 || newW < 1) return fail(HPE_ERR_INVALID, "image too thin");
+    const double fy = (double)newH / (double)H, fx = (double)newW / (double)W;  // actual_factor [y, x]
+    const double cy = std::nearbyint(H / 2.0), cx = std::nearbyint(W / 2.0);     // np.round: half to even
+    const int csx = (int)std::nearbyint(cx * fx), csy = (int)std::nearbyint(cy * fy);
+    const int margin = S / 2;
+    const int start_x = csx + margin - margin, start_y = csy + margin - margin;  // center_pad - margin
+    proc_param[0] = start_x;
+    proc_param[1] = start_y;
+    proc_param[2] = start_x + 2 * margin;
+    proc_param[3] = start_y + 2 * margin;
+    proc_param[4] = S;
+    HIP_TRY(hpe_launch_preprocess_u8(img, H, W, C, newH, newW, start_x, start_y, margin, out224, S, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_get_original(const float* verts, const float* cam, const float* joints2d, int B, int P, int K, const int start_pt[2],
+                     float scale, int img_size, float* vert_shifted, float cam_for_render[3], float* kp_original_host,
+                     const float* joints2d_host, void* stream) {
+    if (!verts || !cam || !vert_shifted || !cam_for_render || !start_pt || B < 1 || P < 1 || scale <= 0.f || img_size < 1)
+        return fail(HPE_ERR_INVALID, "bad argument");
+    (void)joints2d;
+    const float flength = 500.f;
+    const float undo = 1.f / scale;
+    HIP_TRY(hpe_launch_shift_verts(verts, cam, B, P, flength, (float)img_size, vert_shifted, static_cast<hipStream_t>(stream)));
+    // renderer.py:273-276
+    const float pp = img_size / 2.f;
+    cam_for_render[0] = flength * undo;
+    cam_for_render[1] = (pp + (start_pt[0] - 0.5f * img_size)) * undo;
+    cam_for_render[2] = (pp + (start_pt[1] - 0.5f * img_size)) * undo;
+    // renderer.py:281-282: kp_original = (joints + start_pt - margin) * undo_scale (host arrays, K x 2 per image)
+    if (kp_original_host && joints2d_host) {
+        const int margin = img_size / 2;
+        for (int i = 0; i < B * K; ++i) {
+            kp_original_host[2 * i] = (joints2d_host[2 * i] + start_pt[0] - margin) * undo;
+            kp_original_host[2 * i + 1] = (joints2d_host[2 * i + 1] + start_pt[1] - margin) * undo;
+        }
+    }
+    return HPE_OK;
+}
+
 int hpe_kp_loss(const float* kp_gt, const float* kp_pred, int B, int K, float* out, void* stream) {
     if (!kp_gt || !kp_pred || !out || B < 1 || K < 1) return fail(HPE_ERR_INVALID, "bad argument");
     HIP_TRY(hpe_launch_kp_loss(kp_gt, kp_pred, B * K, out, static_cast<hipStream_t>(stream)));

@@ -79,3 +79,9 @@ hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* 
 size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P);
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
                                 hipStream_t st);
+
+// prepost.hip
+hipError_t hpe_launch_preprocess_u8(const unsigned char* img, int H, int W, int C, int newH, int newW, int start_x, int start_y,
+                                    int margin, float* out, int S, hipStream_t st);
+hipError_t hpe_launch_shift_verts(const float* verts, const float* cam, int B, int P, float flength, float img_size, float* out,
+                                  hipStream_t st);

@@ -137,6 +137,18 @@ int hpe_kp_loss(const float* kp_gt_dev, const float* kp_pred_dev, int B, int K, 
 int hpe_mesh_loss(hpe_ctx* ctx, const float* seg_dev, const float* verts2d_dev, int B, int H, int W, int P, float* out_dev,
                   void* stream);
 
+/* -- the steps right before / after the path -------------------------- */
+/* preprocess_image (preview.py:18-35) = resize_img + scale_and_crop (src/util/image.py:7-39) + [-1,1] normalisation,
+ * fused: img_dev uint8 [H,W,C] (C = 3 or 4, RGB first) -> out224_dev float [224,224,3].
+ * proc_param (host, out) = {start_pt.x, start_pt.y, end_pt.x, end_pt.y, img_size}; scale = 224 / max(H, W). */
+int hpe_preprocess_u8(const unsigned char* img_dev, int H, int W, int C, float* out224_dev, int proc_param[5], void* stream);
+/* get_original (src/util/renderer.py:260-283): vert_shifted_dev [B,P,3] = verts + [tx, ty, 500 / (0.5*img_size*s)];
+ * cam_for_render (host, out) = {flength/scale, principal point x, y in the original image};
+ * kp_original_host [B*K*2] = (joints2d_host + start_pt - img_size/2) / scale (both optional host arrays). */
+int hpe_get_original(const float* verts_dev, const float* cam_dev, const float* unused_dev, int B, int P, int K,
+                     const int start_pt[2], float scale, int img_size, float* vert_shifted_dev, float cam_for_render[3],
+                     float* kp_original_host, const float* joints2d_host, void* stream);
+
 /* -- test / measurement hooks -------------------------------------------------------------------- */
 /* Run loaded conv layer `idx` (+BN, optional residual, optional ReLU) on x_dev [B,Hin,Hin,Cin] ->
  * y_dev [B,Hout,Hout,Cout]; for idx 0 the input is the raw [B,224,224,3] image and y is the
