@@ -172,6 +172,16 @@ def main():
                              "bytes_per_launch": nbytes, "mfma_tflops": round(achieved, 1)})
             roofline.pop("flop_per_launch")
             roofline["serial"] = {"sum_of_53_launch_ms": round(ts["conv_ms"], 4)}
+        if args.encoder_dtype == "fp32":
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run
+            # inside the timed region); scaled by batch, null if no measurement of this build family is committed.
+            import glob
+
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*final_conv_hbm_traffic.json")))
+            if cands:
+                tj = json.load(open(cands[-1]))
+                roofline["traffic"] = round(tj["total_bytes"] * B / tj["batch"])
+                roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT)
         phase = {"encoder_ms": round(tm["encoder_ms"], 3), "regress_smpl_ms": round(tm["regress_smpl_ms"], 3),
                  "step_ms_events": round(tm["total_ms"], 3)}
         eng.enable_timing(0)
