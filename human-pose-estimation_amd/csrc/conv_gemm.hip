@@ -9,16 +9,24 @@
 // the bottleneck fused in the epilogue, and the three Dense layers of RegressionNetwork
 // (reference: src/models.py:60-74; y = x @ kernel + bias is the scale == 1 case).
 //
+// Two kernels share the tiling and the epilogue:
+//   conv_gemm_f32_dma_kernel  (default)  LDS-DMA staged: global_load_lds_dwordx4 writes the k-slabs straight into LDS,
+//                                        bank spread by an XOR swizzle on the per-lane source address.
+//   conv_gemm_f32_kernel      (HPE_STAGE=reg, kept for A/B and for the schedule ablations of DESIGN.md §4)
+//                                        register staged: global_load_dwordx4 -> VGPR -> ds_write_b128, padded LDS pitch.
+//
 // CDNA4 mapping
 //   * v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (64 FLOP/clk/SIMD = the fp32 roofline, 157.3 TF).
 //     Lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31].
 //   * A (activations) and W (weights, pre-packed [n][k] on the host at load time) are both staged in LDS
-//     as [row][32 k] slabs with a 36-float row pitch: one ds_read_b128 per lane then feeds FOUR MFMAs
+//     as [row][32 k] slabs (one 128-B line per row): one ds_read_b128 per lane then feeds FOUR MFMAs
 //     (lanes 0-31 hold k = 8g..8g+3, lanes 32-63 hold k = 8g+4..8g+7 -- k is only a summation label,
-//     A and B use the same labelling) and the pitch makes the 16-lane b128 groups conflict-free.
-//   * global->LDS is register staged (16 B/lane, a full 128-B line per 8 lanes) and double buffered:
-//     the loads of slab s+1 are in flight while slab s is multiplied; one barrier per slab.
-//   * 64-wide waves in a WM x WN grid, each wave owns an (MT*32) x (NT*32) accumulator block.
+//     A and B use the same labelling); the 16-lane b128 groups are bank-conflict-free (36-float pitch in the
+//     register-staged kernel, source-side XOR swizzle in the DMA kernel).
+//   * double buffered: the loads of slab s+1 are in flight while slab s is multiplied; one barrier per slab.
+//   * 64-wide waves in a WM x WN grid, each wave owns an (MT*32) x (NT*32) accumulator block; 4 or 8 waves.
+//   * epilogue: BN scale/shift in registers, transpose through the (free) staging LDS, 16 B/lane row stores with the
+//     residual read the same way.
 //   * blockIdx -> tile mapping is XCD-aware: the N-tiles that share an A row-panel are consecutive
 //     on ONE XCD (blocks b, b+8, ... share an L2), so the panel is fetched from HBM once.
 #include <hip/hip_runtime.h>
