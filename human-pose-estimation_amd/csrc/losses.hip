@@ -198,14 +198,106 @@ __global__ __launch_bounds__(256) void nn_b2a_kernel(const float* __restrict__ p
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blk_off + blockIdx.x] = s;
 }
 
+// silhouette bitmap: bits[b][y][w] bit x%64 of word x/64 is set iff seg[b][y][x] > 0; one wave builds one word with a ballot
+__global__ __launch_bounds__(256) void sil_bitmap_kernel(const float* __restrict__ seg, int H, int W, int WW,
+                                                         unsigned long long* __restrict__ bits, long nwords) {
+    const long word = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= nwords) return;
+    const int lane = threadIdx.x & 63;
+    const int w = (int)(word % WW);
+    const long row = word / WW;  // b * H + y
+    const int x = w * 64 + lane;
+    const float v = (x < W) ? seg[row * W + x] : 0.f;
+    const unsigned long long m = __ballot(v > 0.f);
+    if (lane == 0) bits[word] = m;
+}
+
+// direction B -> A on the pixel grid: the silhouette points are integer pixels, so for one vertex only TWO pixels per image
+// row can be its nearest neighbour (the closest set bit on either side of its x), and rows farther than the best distance
+// found so far cannot win.  Rows are visited outwards from the vertex' own row; the candidate distance is still the
+// reference's expanded fp32 form and ties are resolved to the lowest (y, x) = lowest tf.where index, so the chosen pixel is
+// the one tf.argmin picks.  ~2*sqrt(d) rows x 2 candidates per vertex instead of P_i (~12k) candidates.
+#define NN_MAXWW 8
+__global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
+                                                          const float* __restrict__ v2d, int H, int W, int WW, int P,
+                                                          float* __restrict__ partial, int nblk, int blk_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sbits[];  // [H][WW]
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int cnt = counts[b];
+    for (int i = threadIdx.x; i < H * WW; i += 256) sbits[i] = bits[(size_t)b * H * WW + i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float contrib = 0.f;
+    if (p < P && cnt > 0) {
+        const float bx = v2d[((size_t)b * P + p) * 2], by = v2d[((size_t)b * P + p) * 2 + 1];
+        const float bb = bx * bx + by * by;
+        const int x0 = min(max((int)rintf(bx), 0), W - 1);
+        const int y0 = min(max((int)rintf(by), 0), H - 1);
+        float best = 3.4e38f;
+        int cx = 0, cy = 0;
+        auto try_pixel = [&](int x, int y) {
+            const float ax = (float)x, ay = (float)y;
+            const float d = (-2.0f * (ax * bx + ay * by) + (ax * ax + ay * ay)) + bb;
+            if (d < best || (d == best && (y < cy || (y == cy && x < cx)))) {
+                best = d;
+                cx = x;
+                cy = y;
+            }
+        };
+        auto scan_row = [&](int y) {
+            const unsigned long long* row = sbits + y * WW;
+            // nearest set bit at or left of x0
+            for (int i = x0 >> 6; i >= 0; --i) {
+                unsigned long long m = row[i];
+                if (i == (x0 >> 6)) m &= (~0ull >> (63 - (x0 & 63)));
+                if (m) {
+                    try_pixel(i * 64 + 63 - __clzll(m), y);
+                    break;
+                }
+            }
+            // nearest set bit right of x0
+            const int x1 = x0 + 1;
+            for (int i = x1 >> 6; i < WW; ++i) {
+                unsigned long long m = row[i];
+                if (i == (x1 >> 6)) m &= (~0ull << (x1 & 63));
+                if (m) {
+                    try_pixel(i * 64 + __ffsll((long long)m) - 1, y);
+                    break;
+                }
+            }
+        };
+        scan_row(y0);
+        bool up = true, down = true;
+        for (int k = 1; (up || down) && k < H; ++k) {
+            if (down) {
+                const int y = y0 + k;
+                const float dy = (float)y - by;
+                if (y >= H || dy * dy > best + 0.25f) down = false;  // expanded-form rounding error is << 0.25 here
+                else scan_row(y);
+            }
+            if (up) {
+                const int y = y0 - k;
+                const float dy = by - (float)y;
+                if (y < 0 || dy * dy > best + 0.25f) up = false;
+                else scan_row(y);
+            }
+        }
+        const float dx = bx - (float)cx, dy = by - (float)cy;
+        contrib = sqrtf(dx * dx + dy * dy);
+    }
+    const float s = block_sum_256(contrib, red);
+    if (threadIdx.x == 0) partial[(size_t)b * nblk + blk_off + blockIdx.x] = s;
+}
+
 // out[0] = sum_b ( sum of image b's partials ) / (3 + P), images added in index order (src/ops.py:129-136)
-__global__ __launch_bounds__(256) void mesh_loss_finish_kernel(const float* __restrict__ partial, int B, int nblk, int P,
+__global__ __launch_bounds__(256) void mesh_loss_finish_kernel(const float* __restrict__ partial, int B, int nblk, int nused, int P,
                                                                float* __restrict__ out) {
     __shared__ float red[4];
     float total = 0.f;
     for (int b = 0; b < B; ++b) {
         float v = 0.f;
-        for (int i = threadIdx.x; i < nblk; i += 256) v += partial[(size_t)b * nblk + i];
+        for (int i = threadIdx.x; i < nused; i += 256) v += partial[(size_t)b * nblk + i];
         const float s = block_sum_256(v, red);
         total += s / (float)(3 + P);
     }
@@ -221,27 +313,44 @@ hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* 
 
 size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P) {
     const int HW = H * W;
-    const int nblk = (HW + 1023) / 1024 + (P + 1023) / 1024;
-    return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64;
+    const int nblk = (HW + 1023) / 1024 + (P + 255) / 256;
+    const size_t bitmap_floats = (size_t)B * H * ((W + 63) / 64) * 2;
+    return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64 + bitmap_floats + 16;
 }
 
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
                                 hipStream_t st) {
     const int HW = H * W;
-    const int nA = (HW + 1023) / 1024, nB = (P + 1023) / 1024;
-    const int nblk = nA + nB;
+    const int WW = (W + 63) / 64;
+    const bool grid_path = WW <= NN_MAXWW && (size_t)H * WW * 8 <= 64 * 1024;
+    const int nA = (HW + 1023) / 1024, nB = grid_path ? (P + 255) / 256 : (P + 1023) / 1024;
+    const int nblk = (HW + 1023) / 1024 + (P + 255) / 256;  // workspace pitch (>= nA + nB)
     float* pts = ws;
     float* partial = pts + (size_t)B * HW * 2;
     int* counts = reinterpret_cast<int*>(partial + (size_t)B * nblk);
+    // 8-byte aligned bitmap after the counts
+    size_t off = (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 2;
+    off = (off + 1) & ~(size_t)1;
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws + off);
     hipLaunchKernelGGL(sil_compact_kernel, dim3(B), dim3(256), 0, st, seg, HW, W, pts, counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(nn_b2a_kernel, dim3(nB, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk, nA);
+    if (grid_path) {
+        const long nwords = (long)B * H * WW;
+        hipLaunchKernelGGL(sil_bitmap_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, st, seg, H, W, WW, bits, nwords);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(nB, B), dim3(256), (size_t)H * WW * 8, st, bits, counts, v2d, H, W, WW, P, partial,
+                           nblk, nA);
+    } else {
+        hipLaunchKernelGGL(nn_b2a_kernel, dim3(nB, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk, nA);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, B, nblk, P, out);
+    // zero-fill is not needed: every partial slot in [0, nA + nB) is written; finish sums exactly those
+    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, B, nblk, nA + nB, P, out);
     return hipGetLastError();
 }
