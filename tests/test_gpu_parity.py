@@ -248,6 +248,27 @@ def test_kp_loss(assets):
     assert zero == 0.0
 
 
+def test_mesh_loss_degenerate_and_far(engine, assets):
+    """grid / bitmap search edge cases: mesh collapsed into one cell, mesh far outside the image, single-pixel silhouette,
+    exact ties (duplicate vertices, pixels equidistant from two vertices)."""
+    B = 4
+    g = np.random.Generator(np.random.Philox(77))
+    seg = np.zeros((B, 224, 224, 1), np.float32)
+    seg[0, 60:160, 80:150] = 1.0
+    seg[1, 10, 200] = 1.0
+    seg[2, ::7, ::5] = 1.0
+    seg[3, 100:120, 100:120] = 1.0
+    sil_pred = np.zeros((B, 6890, 2), np.float32)
+    sil_pred[0] = 112.0 + g.normal(0, 0.5, (6890, 2))                      # collapsed mesh
+    sil_pred[1] = g.uniform(-300, 600, (6890, 2))                          # mostly outside the image / the grid apron
+    sil_pred[2] = np.round(g.uniform(0, 224, (6890, 2)))                   # integer coordinates: many exact ties
+    sil_pred[2, 1000:2000] = sil_pred[2, :1000]                            # duplicate vertices
+    sil_pred[3] = g.uniform(90, 130, (6890, 2))
+    ref = O.mesh_reprojection_loss(O.silhouette_points(seg), sil_pred, B)
+    out = float(cpu(hpe_amd.mesh_reprojection_loss(engine, gpu(seg), gpu(sil_pred))))
+    assert abs(out - ref) / abs(ref) < 1e-5, (out, ref)
+
+
 def test_mesh_loss(engine, assets):
     B = 2
     seg, _ = synthetic.make_lsp_targets(B, seed=14)
