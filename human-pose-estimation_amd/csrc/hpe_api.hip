@@ -809,12 +809,11 @@ int hpe_preprocess_u8(const unsigned char* img, int H, int W, int C, float* out2
     return HPE_OK;
 }
 
-int hpe_get_original(const float* verts, const float* cam, const float* joints2d, int B, int P, int K, const int start_pt[2],
-                     float scale, int img_size, float* vert_shifted, float cam_for_render[3], float* kp_original_host,
-                     const float* joints2d_host, void* stream) {
+int hpe_get_original(const float* verts, const float* cam, int B, int P, int K, const int start_pt[2], float scale, int img_size,
+                     float* vert_shifted, float cam_for_render[3], float* kp_original_host, const float* joints2d_host,
+                     void* stream) {
     if (!verts || !cam || !vert_shifted || !cam_for_render || !start_pt || B < 1 || P < 1 || scale <= 0.f || img_size < 1)
         return fail(HPE_ERR_INVALID, "bad argument");
-    (void)joints2d;
     const float flength = 500.f;
     const float undo = 1.f / scale;
     HIP_TRY(hpe_launch_shift_verts(verts, cam, B, P, flength, (float)img_size, vert_shifted, static_cast<hipStream_t>(stream)));

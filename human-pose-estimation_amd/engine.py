@@ -167,8 +167,12 @@ class HpeEngine(object):
         _lib.check(self.lib.hpe_forward(self._h, images.data_ptr(), B, arr, n_outs, self._stream()))
         return outs
 
-    def make_forward_plan(self, B, all_stages=False, want=DEFAULT_OUTPUTS):
-        """Pre-allocate outputs once; returns (callable(images), outputs) -- the steady-state serving path."""
+    def make_forward_plan(self, B, all_stages=False, want=DEFAULT_OUTPUTS, graph=False):
+        """Pre-allocate outputs once; returns (callable(images), outputs) -- the steady-state serving path.
+        graph=True captures the whole forward (all kernel launches, including the fork/join of the batch-chunk streams)
+        into a hipGraph through torch.cuda.CUDAGraph: the callable then copies `images` into a static input buffer and
+        replays the graph -- one host call per batch instead of ~75 launches (what matters for small batches)."""
+        torch = _torch()
         n_outs = self.num_stage if all_stages else 1
         outs = []
         arr = (_lib.HpeOutputs * n_outs)()
@@ -178,11 +182,36 @@ class HpeEngine(object):
             arr[i] = o
         lib, h = self.lib, self._h
 
-        def run(images):
+        def launch(images):
             _lib.check(lib.hpe_forward(h, images.data_ptr(), B, arr, n_outs, self._stream()))
+
+        if not graph:
+
+            def run(images):
+                launch(images)
+                return outs
+
+            return run, outs
+
+        static_in = torch.zeros((B, 224, 224, 3), dtype=torch.float32, device=self.tdev)
+        self.enable_timing(0)  # event timing cannot be captured
+        side = torch.cuda.Stream(device=self.tdev)
+        side.wait_stream(torch.cuda.current_stream(self.tdev))
+        with torch.cuda.stream(side):  # warm-up outside capture (lazy allocations such as module loading)
+            launch(static_in)
+        torch.cuda.current_stream(self.tdev).wait_stream(side)
+        torch.cuda.synchronize(self.tdev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            launch(static_in)
+
+        def run_graph(images):
+            static_in.copy_(images, non_blocking=True)
+            g.replay()
             return outs
 
-        return run, outs
+        run_graph.graph = g  # keep alive
+        return run_graph, outs
 
     def encoder(self, images):
         images = _require_cuda_tensor(images, "images", (224, 224, 3))

@@ -55,6 +55,6 @@ def get_original(proc_param, verts, cam, joints, img_size=224):
     sp = (C.c_int * 2)(int(proc_param["start_pt"][0]), int(proc_param["start_pt"][1]))
     with torch.cuda.device(v.device):
         st = C.c_void_p(torch.cuda.current_stream(v.device).cuda_stream)
-        _lib.check(_lib.load().hpe_get_original(v.data_ptr(), c.data_ptr(), None, B, P, K, sp, float(proc_param["scale"]), img_size,
+        _lib.check(_lib.load().hpe_get_original(v.data_ptr(), c.data_ptr(), B, P, K, sp, float(proc_param["scale"]), img_size,
                                                 out.data_ptr(), cfr, kp.ctypes.data_as(C.c_void_p), j.ctypes.data_as(C.c_void_p), st))
     return np.array(list(cfr), np.float32), (out[0] if single else out), (kp[0] if single else kp)

@@ -145,9 +145,9 @@ int hpe_preprocess_u8(const unsigned char* img_dev, int H, int W, int C, float* 
 /* get_original (src/util/renderer.py:260-283): vert_shifted_dev [B,P,3] = verts + [tx, ty, 500 / (0.5*img_size*s)];
  * cam_for_render (host, out) = {flength/scale, principal point x, y in the original image};
  * kp_original_host [B*K*2] = (joints2d_host + start_pt - img_size/2) / scale (both optional host arrays). */
-int hpe_get_original(const float* verts_dev, const float* cam_dev, const float* unused_dev, int B, int P, int K,
-                     const int start_pt[2], float scale, int img_size, float* vert_shifted_dev, float cam_for_render[3],
-                     float* kp_original_host, const float* joints2d_host, void* stream);
+int hpe_get_original(const float* verts_dev, const float* cam_dev, int B, int P, int K, const int start_pt[2], float scale,
+                     int img_size, float* vert_shifted_dev, float cam_for_render[3], float* kp_original_host,
+                     const float* joints2d_host, void* stream);
 
 /* -- test / measurement hooks -------------------------------------------------------------------- */
 /* Run loaded conv layer `idx` (+BN, optional residual, optional ReLU) on x_dev [B,Hin,Hin,Cin] ->

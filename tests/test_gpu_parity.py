@@ -302,6 +302,24 @@ def test_val_step_losses_match_oracle(assets):
     assert tuple(r["pred_keypoints"].shape) == (3, 3, 19, 2) and tuple(r["generated_verts"].shape) == (3, 3, 6890, 3)
 
 
+def test_graph_replay_matches_eager(engine, assets):
+    """hpe_forward only enqueues on the given stream (plus fork/join of its chunk streams), so it can be captured into a
+    hipGraph; replay must give the eager result bit for bit."""
+    import torch
+
+    img = gpu(synthetic.make_images(2, seed=71))
+    eager = engine.forward(img)[0]
+    run, outs = engine.make_forward_plan(2, graph=True)
+    o = run(img)[0]
+    torch.cuda.synchronize()
+    for k in ("verts", "joints", "theta", "kp2d"):
+        np.testing.assert_array_equal(cpu(o[k]), cpu(eager[k]))
+    img2 = gpu(synthetic.make_images(2, seed=72))
+    o2 = run(img2)[0]
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(cpu(o2["theta"]), cpu(engine.forward(img2)[0]["theta"]))
+
+
 # ------------------------------------------------------------------------------------------- bf16 encoder (config 4)
 def test_bf16_encoder_variant(assets):
     """BASELINE config 4: bf16 encoder (bf16 MFMA, fp32 accumulate) + fp32 regressor / SMPL.  Parity is REPORTED against
