@@ -174,7 +174,7 @@ int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
     return HPE_OK;
 }
 
-int pick_tile(int M, int N) {
+int pick_tile(int M, int N, int K) {
     // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
     static int force_wide = -2, force_narrow = -2;
     if (force_wide == -2) {
@@ -189,9 +189,15 @@ int pick_tile(int M, int N) {
     // Measured on MI355X (profiles/r01/d_tile_sweep.txt): with LDS-DMA staging the small tiles with 3-5 workgroups
     // per CU beat 128x128 at 2 per CU except on the huge-M layers of stages 2-3.
     if (!wide) return TILE_128x64;
-    const long big = (long)((M + 63) / 64) * ((N + 127) / 128);
+    static int shortk = -2;
+    if (shortk == -2) {
+        const char* e = getenv("HPE_SHORTK_TILE");
+        shortk = e ? atoi(e) : TILE_128x128_W8;
+    }
+    // K <= 64 (the 64 -> 256 expand / projection layers of stage 2): two k-slabs only, the launch is all epilogue ->
+    // the widest rows per workgroup and 8 waves to issue the row stores win (d_tile_sweep.txt, res2*_branch2c / branch1)
+    if (K <= 64 && M >= 150000) return shortk;
     if (M >= 150000) return TILE_64x128;
-    (void)big;
     return TILE_64x64;
 }
 
@@ -256,7 +262,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         p.cin_slabs = s.cin / 64;
         return hpe_launch_gemm_bf16(p, mode, pick_tile_bf16(p.M, p.N), st);
     }
-    return hpe_launch_gemm(p, mode, pick_tile(p.M, p.N), st);
+    return hpe_launch_gemm(p, mode, pick_tile(p.M, p.N, p.K), st);
 }
 
 hipError_t run_dense(const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
