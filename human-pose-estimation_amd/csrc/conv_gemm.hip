@@ -116,6 +116,24 @@ __device__ __forceinline__ SlabPos slab_first(const GemmArgs& p) {
 }
 
 template <int MODE>
+__device__ __forceinline__ SlabPos slab_seek(const GemmArgs& p, int slab) {
+    SlabPos sp;
+    sp.tap = 0;
+    sp.cs = 0;
+    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
+        sp.off = slab * BK;
+    } else if (MODE == GEMM_CONV3) {
+        sp.tap = slab / p.cin_slabs;
+        sp.cs = slab - sp.tap * p.cin_slabs;
+        const int kh = sp.tap / 3;
+        sp.off = ((kh - 1) * p.Wi + (sp.tap - kh * 3 - 1)) * p.Cin + sp.cs * BK;
+    } else {
+        sp.off = slab * p.Wi * 4;
+    }
+    return sp;
+}
+
+template <int MODE>
 __device__ __forceinline__ f32x4 load_a(const GemmArgs& p, const RowAddr& r, const SlabPos& sp) {
     if (MODE == GEMM_CONV3) {
         // branch-free: out-of-image taps read the (always valid) centre pixel and are zeroed by a select
@@ -463,132 +481,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
 // register-staged kernel comes from an XOR swizzle applied on the per-lane SOURCE address instead:
 // LDS chunk c of row r holds logical chunk c ^ ((r >> 1) & 7), and the fragment read applies the same XOR, which
 // makes every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row.
-template <int MODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
+// Epilogue shared by the DMA kernel and the split-K fix-up kernel: BN scale/shift in registers, transpose through LDS,
+// rows leave as 16 B per lane with the residual read the same way.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const GemmArgs& p, float* lds, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0, int t,
+                                              int lane, int wm, int wn) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
-    constexpr int NW = WM * WN;        // waves per workgroup (4 or 8)
-    constexpr int NTHR = 64 * NW;
-    constexpr int AP = BM / (8 * NW);  // DMA instructions per wave for the A rows of one slab
-    constexpr int BP = BN / (8 * NW);
+    constexpr int NTHR = 64 * WM * WN;
     constexpr int EP = BN + 4;
-    constexpr int BUF = (BM + BN) * BK;  // floats per staging buffer (unpadded rows)
-    constexpr int LDS_FLOATS = (2 * BUF > BM * EP) ? 2 * BUF : BM * EP;
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-    static_assert(AP >= 1 && BP >= 1, "tile too small for the wave count");
-
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-
-    const int total = p.n_mtiles * p.n_ntiles;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int q = total >> 3, rr = total & 7;
-    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int mtile = swz / p.n_ntiles;
-    const int ntile = swz - mtile * p.n_ntiles;
-    const int m0 = mtile * BM;
-    const int n0 = ntile * BN;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WN;
-    const int wn = wave - wm * WN;
-
-    // ---- DMA sources: instruction i of wave w fills rows (4i + w) * 8 + (lane >> 3), LDS chunk lane & 7
-    const int drow = lane >> 3;
-    RowAddr arow[AP];
-    const float* wsrc[BP];
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int r = (NW * i + wave) * 8 + drow;
-        const int lc = (lane & 7) ^ ((r >> 1) & 7);
-        arow[i] = make_row<MODE>(p, m0 + r, lc * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-        const int r = (NW * i + wave) * 8 + drow;
-        const int lc = (lane & 7) ^ ((r >> 1) & 7);
-        wsrc[i] = p.w + (size_t)(n0 + r) * p.ldw + lc * 4;
-    }
-
-    // ---- fragment read offsets: row r of the wave tile, logical chunk 2g + (lane >> 5)
-    int a_row[MT], b_row[NT], a_x[MT], b_x[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int r = (wm * MT + i) * 32 + (lane & 31);
-        a_row[i] = r * BK;
-        a_x[i] = (r >> 1) & 7;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int r = (wn * NT + j) * 32 + (lane & 31);
-        b_row[j] = (BM + r) * BK;
-        b_x[j] = (r >> 1) & 7;
-    }
-    const int hi = lane >> 5;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int S = p.K / BK;
-    SlabPos sp = slab_first<MODE>(p);
-
-    auto issue_dma = [&](int slab, int buf) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const float* src;
-            if (MODE == GEMM_CONV3) {
-                const bool ok = (arow[i].mask >> sp.tap) & 1u;
-                src = ok ? (p.x + (arow[i].base + sp.off)) : p.zero;
-            } else {
-                src = p.x + (arow[i].base + sp.off);
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + buf + (NW * i + wave) * 8 * BK), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + slab * BK),
-                                             (__attribute__((address_space(3))) void*)(lds + buf + (BM + (NW * i + wave) * 8) * BK), 16, 0,
-                                             0);
-        }
-    };
-
-    issue_dma(0, 0);
-    __syncthreads();  // emits s_waitcnt vmcnt(0) before the barrier: the DMA has landed for every wave
-
-    for (int s = 0; s < S; ++s) {
-        const int cur = (s & 1) * BUF;
-        if (s + 1 < S) {
-            slab_advance<MODE>(p, sp);
-            issue_dma(s + 1, BUF - cur);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 fa[MT], fb[NT];
-            const int lc = 2 * g + hi;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&lds[cur + a_row[i] + ((lc ^ a_x[i]) << 2)]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&lds[cur + b_row[j] + ((lc ^ b_x[j]) << 2)]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue (identical to the register-staged kernel)
     {
         const int col_l = lane & 31;
         const int row_l = 4 * (lane >> 5);
@@ -646,6 +547,200 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
     }
 }
 
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma_kernel(GemmArgs p) {
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int NW = WM * WN;        // waves per workgroup (4 or 8)
+    constexpr int NTHR = 64 * NW;
+    constexpr int AP = BM / (8 * NW);  // DMA instructions per wave for the A rows of one slab
+    constexpr int BP = BN / (8 * NW);
+    constexpr int EP = BN + 4;
+    constexpr int BUF = (BM + BN) * BK;  // floats per staging buffer (unpadded rows)
+    constexpr int LDS_FLOATS = (2 * BUF > BM * EP) ? 2 * BUF : BM * EP;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(AP >= 1 && BP >= 1, "tile too small for the wave count");
+
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    // Small grids (small batches, the Dense layers) are cut along K: workgroup bid owns K-slice bid % split_k of tile
+    // bid / split_k, stores raw accumulators, and conv_gemm_fixup_kernel reduces the slices (fixed order) and runs the
+    // epilogue.  split_k == 1: whole tiles with the XCD-aware bijective remap.
+    const int total = p.n_mtiles * p.n_ntiles;
+    const int bid = blockIdx.x;
+    int tile, ks0 = 0, ks1 = p.K / BK, part = -1;
+    if (p.split_k > 1) {
+        tile = bid / p.split_k;
+        part = bid - tile * p.split_k;
+        const int S = p.K / BK;
+        ks0 = (int)((long)part * S / p.split_k);
+        ks1 = (int)((long)(part + 1) * S / p.split_k);
+    } else {
+        const int xcd = bid & 7;
+        const int q = total >> 3, rr = total & 7;
+        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int mtile = tile / p.n_ntiles;
+    const int ntile = tile - mtile * p.n_ntiles;
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+
+    // ---- DMA sources: instruction i of wave w fills rows (4i + w) * 8 + (lane >> 3), LDS chunk lane & 7
+    const int drow = lane >> 3;
+    RowAddr arow[AP];
+    const float* wsrc[BP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int r = (NW * i + wave) * 8 + drow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        arow[i] = make_row<MODE>(p, m0 + r, lc * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int r = (NW * i + wave) * 8 + drow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[i] = p.w + (size_t)(n0 + r) * p.ldw + lc * 4;
+    }
+
+    // ---- fragment read offsets: row r of the wave tile, logical chunk 2g + (lane >> 5)
+    int a_row[MT], b_row[NT], a_x[MT], b_x[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = (wm * MT + i) * 32 + (lane & 31);
+        a_row[i] = r * BK;
+        a_x[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = (wn * NT + j) * 32 + (lane & 31);
+        b_row[j] = (BM + r) * BK;
+        b_x[j] = (r >> 1) & 7;
+    }
+    const int hi = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    SlabPos sp = slab_seek<MODE>(p, ks0);
+
+    auto issue_dma = [&](int slab, int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const float* src;
+            if (MODE == GEMM_CONV3) {
+                const bool ok = (arow[i].mask >> sp.tap) & 1u;
+                src = ok ? (p.x + (arow[i].base + sp.off)) : p.zero;
+            } else {
+                src = p.x + (arow[i].base + sp.off);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (NW * i + wave) * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + slab * BK),
+                                             (__attribute__((address_space(3))) void*)(lds + buf + (BM + (NW * i + wave) * 8) * BK), 16, 0,
+                                             0);
+        }
+    };
+
+    issue_dma(ks0, 0);
+    __syncthreads();  // emits s_waitcnt vmcnt(0) before the barrier: the DMA has landed for every wave
+
+    for (int s = ks0; s < ks1; ++s) {
+        const int cur = ((s - ks0) & 1) * BUF;
+        if (s + 1 < ks1) {
+            slab_advance<MODE>(p, sp);
+            issue_dma(s + 1, BUF - cur);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 fa[MT], fb[NT];
+            const int lc = 2 * g + hi;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&lds[cur + a_row[i] + ((lc ^ a_x[i]) << 2)]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&lds[cur + b_row[j] + ((lc ^ b_x[j]) << 2)]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    if (part >= 0) {
+        // split-K slice: raw accumulators -> workspace [tile][slice][register quad][thread] (16 B per lane, coalesced)
+        f32x4* dst = reinterpret_cast<f32x4*>(p.partial) + (size_t)(tile * p.split_k + part) * (MT * NT * 4 * NTHR) + t;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+                    dst[((i * NT + j) * 4 + qd) * NTHR] = v;
+                }
+        return;
+    }
+    conv_epilogue<BM, BN, WM, WN>(p, lds, acc, m0, n0, t, lane, wm, wn);
+}
+
+// Reduces the K-slices of every tile (fixed order -> bitwise reproducible) and runs the normal epilogue.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_fixup_kernel(GemmArgs p) {
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int EP = BN + 4;
+    __shared__ __attribute__((aligned(16))) float lds[BM * EP];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int tile = blockIdx.x;
+    const int mtile = tile / p.n_ntiles;
+    const int ntile = tile - mtile * p.n_ntiles;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + (size_t)tile * p.split_k * (MT * NT * 4 * NTHR) + t;
+    for (int part = 0; part < p.split_k; ++part) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 v = src[(size_t)part * (MT * NT * 4 * NTHR) + ((i * NT + j) * 4 + qd) * NTHR];
+                    acc[i][j][4 * qd] += v.x;
+                    acc[i][j][4 * qd + 1] += v.y;
+                    acc[i][j][4 * qd + 2] += v.z;
+                    acc[i][j][4 * qd + 3] += v.w;
+                }
+    }
+    conv_epilogue<BM, BN, WM, WN>(p, lds, acc, mtile * BM, ntile * BN, t, lane, wm, wn);
+}
+
 int stage_variant() {
     static int v = -1;
     if (v < 0) {
@@ -665,17 +760,39 @@ int sched_variant() {
     return v;
 }
 
+int splitk_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HPE_SPLITK");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
 template <int MODE, int BM, int BN, int WM, int WN>
 hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
     p.n_mtiles = (p.M + BM - 1) / BM;
     p.n_ntiles = (p.N + BN - 1) / BN;
     const int grid = p.n_mtiles * p.n_ntiles;
+    p.split_k = 1;
     if constexpr (WM * WN == 8) {
         hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(512), 0, st, p);
         return hipGetLastError();
     } else {
     if (stage_variant() == 1 && p.zero) {
-        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
+        // latency-bound small grids: cut K so that about one workgroup per CU runs (>= 4 slabs per slice)
+        const int S = p.K / BK;
+        if (p.partial && splitk_enabled() && grid < 128 && S >= 8) {
+            int sk = 256 / grid;
+            if (sk > S / 4) sk = S / 4;
+            if (sk > 16) sk = 16;
+            while (sk > 1 && (size_t)grid * sk * BM * BN > p.partial_floats) --sk;
+            if (sk > 1) p.split_k = sk;
+        }
+        hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid * p.split_k), dim3(256), 0, st, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || p.split_k == 1) return e;
+        hipLaunchKernelGGL((conv_gemm_fixup_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
         return hipGetLastError();
     }
     switch (sched_variant()) {

@@ -135,6 +135,8 @@ struct hpe_ctx {
     std::vector<void*> allocs;
     // batch-chunk streams
     int n_streams = 1;
+    float* partial = nullptr;  // split-K workspace (small grids only run unchunked on the caller's stream)
+    size_t partial_floats = 0;
     int chunk_images = 0;
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
@@ -245,6 +247,10 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     p.cin_slabs = s.cin / 32;
     p.lda = s.cin;
     p.zero = c->zeros;
+    if (B < 64) {  // chunk streams are off below 64 images, so one workspace is enough
+        p.partial = c->partial;
+        p.partial_floats = c->partial_floats;
+    }
     int mode;
     if (idx == 0) {
         mode = GEMM_STEM;
@@ -265,10 +271,12 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     return hpe_launch_gemm(p, mode, pick_tile(p.M, p.N, p.K), st);
 }
 
-hipError_t run_dense(const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
+hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
                      const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
     GemmArgs p{};
     p.zero = shift;  // any readable 16 B: dense mode never takes the zero-page path
+    p.partial = c->partial;  // the Dense layers run on the caller's stream after the chunk streams have joined
+    p.partial_floats = c->partial_floats;
     p.x = x;
     p.w = w;
     p.scale = scale;
@@ -374,13 +382,13 @@ hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features,
 
 // one IEF step on padded theta rows [B, THETA_LD]; P1 = features . W1[:2048] must be current
 hipError_t regress_impl(hpe_ctx* c, const float* th_prev, float* th_next, int B, hipStream_t st) {
-    HIPE(run_dense(th_prev, THETA_LD, B, THETA_LD, c->w1t, 1024, 1024, c->ones, c->b1, c->P1, 1024, 1, c->H1, 1024, st));
-    HIPE(run_dense(c->H1, 1024, B, 1024, c->w2, 1024, 1024, c->ones, c->b2, nullptr, 0, 1, c->H2, 1024, st));
-    return run_dense(c->H2, 1024, B, 1024, c->w3, 128, HPE_THETA_DIM, c->ones, c->b3, th_prev, THETA_LD, 0, th_next, THETA_LD, st);
+    HIPE(run_dense(c, th_prev, THETA_LD, B, THETA_LD, c->w1t, 1024, 1024, c->ones, c->b1, c->P1, 1024, 1, c->H1, 1024, st));
+    HIPE(run_dense(c, c->H1, 1024, B, 1024, c->w2, 1024, 1024, c->ones, c->b2, nullptr, 0, 1, c->H2, 1024, st));
+    return run_dense(c, c->H2, 1024, B, 1024, c->w3, 128, HPE_THETA_DIM, c->ones, c->b3, th_prev, THETA_LD, 0, th_next, THETA_LD, st);
 }
 
 hipError_t features_proj(hpe_ctx* c, const float* features, int B, hipStream_t st) {
-    return run_dense(features, HPE_FEATURE_DIM, B, HPE_FEATURE_DIM, c->w1f, 1024, 1024, c->ones, c->zeros, nullptr, 0, 0, c->P1,
+    return run_dense(c, features, HPE_FEATURE_DIM, B, HPE_FEATURE_DIM, c->w1f, 1024, 1024, c->ones, c->zeros, nullptr, 0, 0, c->P1,
                      1024, st);
 }
 
@@ -670,6 +678,10 @@ int hpe_finalize(hpe_ctx* c) {
             if ((rc = dev_alloc(c, &c->T1, B * 200704, false))) return rc;
             if ((rc = dev_alloc(c, &c->T2, B * 200704, false))) return rc;
             if ((rc = dev_alloc(c, &c->feat, B * HPE_FEATURE_DIM, true))) return rc;
+        }
+        {
+            c->partial_floats = (size_t)512 * 128 * 128;  // 512 slices of the largest tile (32 MB)
+            if ((rc = dev_alloc(c, &c->partial, c->partial_floats, false))) return rc;
         }
         if (c->have_regressor) {
             if ((rc = dev_alloc(c, &c->P1, B * 1024, true))) return rc;

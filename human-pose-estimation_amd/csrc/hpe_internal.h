@@ -19,6 +19,9 @@ struct GemmArgs {
     int relu;
     int Hi, Wi, Cin, Ho, Wo, stride, cin_slabs;
     int n_mtiles, n_ntiles;  // filled by the launcher
+    int split_k;             // filled by the launcher (> 1: small grid cut along K, reduced by the fix-up kernel)
+    float* partial;          // split-K workspace of the launching stream, partial_floats floats; nullptr disables splitting
+    size_t partial_floats;
     const float* zero;       // >= 16 B of zeros in global memory (source of out-of-image taps for the LDS-DMA path)
     unsigned long long* dbg;  // diagnostics only (HPE_ABLATION builds): per-workgroup {shader clocks, 100 MHz ticks}
 };
