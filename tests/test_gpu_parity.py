@@ -389,3 +389,46 @@ def test_full_size_batch_invariance_and_linearity(assets):
     rhs = verts_of(b1) + verts_of(b2)
     assert rel(lhs, rhs) < 2e-6
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------- asset ingestion from files
+def test_predictor_from_files(tmp_path, assets):
+    """Predictor(config) with nothing but paths, like the reference: SMPL model from a (chumpy-free) pickle with scipy-sparse
+    regressors (batch_smpl.py:31-81), mean params next to it (predictor.py:93-95; .npz instead of .h5 -- h5py is absent),
+    weights from <checkpoint_dir>/weights.npz in Keras layouts; BN epsilon of tf.keras >= 2.2 (1.001e-5) exercised too."""
+    import pickle
+
+    import scipy.sparse as sp
+
+    m = assets["smpl"]
+    pkl = dict(m)
+    pkl["J_regressor"] = sp.csc_matrix(m["J_regressor"])
+    pkl["cocoplus_regressor"] = sp.csc_matrix(m["cocoplus_regressor"])
+    model_dir = tmp_path / "models"
+    model_dir.mkdir()
+    with open(model_dir / "model.pkl", "wb") as f:
+        pickle.dump(pkl, f)
+    np.savez(model_dir / "neutral_smpl_mean_params.npz", pose=assets["mean"]["pose"], shape=assets["mean"]["shape"])
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    w = dict(assets["enc"])
+    w.update(assets["reg"])
+    np.savez(ckpt / "weights.npz", **w)
+
+    class Cfg(object):
+        img_size, num_stage, batch_size, data_format = 224, 3, 2, "NCHW"  # the reference transposes itself; input stays NHWC
+        smpl_model_path = str(model_dir / "model.pkl")
+        checkpoint_dir = str(ckpt)
+        bn_eps = 1.001e-5
+
+    p = hpe_amd.Predictor(Cfg())
+    img = synthetic.make_images(2, seed=91)
+    r = p.predict(img)
+    feat = O.resnet50_features(img, assets["enc"], eps=1.001e-5)
+    ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"], features=feat)
+    for k in ("generated_joints", "generated_verts", "generated_cams", "theta"):
+        assert rel(cpu(r[k]), ref[k]) < TOL, k
+    import torch
+
+    r2 = p.predict(torch.from_numpy(img))  # CPU torch tensor input is moved to the device
+    np.testing.assert_array_equal(cpu(r2["theta"]), cpu(r["theta"]))
