@@ -16,7 +16,10 @@ absent -- plain absence, nothing was denied).  The encoder arithmetic is not in 
 all (it is ``tensorflow.keras.applications.ResNet50``, TF pinned by README to 2.0.0-beta1 wrapping
 keras_applications 1.0.8 ``resnet50.py``); its topology is restated here from that published
 definition.  What pins this oracle instead: the closed-form known-answer tests of SURVEY.md §4
-(``tests/test_oracle_kat.py``) and an fp64 run of the same restatement.
+(``tests/test_oracle_kat.py``), an fp64 run of the same restatement, and -- for the encoder topology -- agreement to 1e-9
+(fp64) with an unrelated third-party implementation of ResNet-50 v1, Hugging Face transformers' PyTorch ``ResNetModel``
+with ``downsample_in_bottleneck=True`` (``tests/test_oracle_vs_hf_resnet.py``).  None of these is the reference's own
+TensorFlow run, hence 'unpinned'.
 
 Every function cites the reference lines it follows.  ``dtype`` is float32 for the reference-equivalent
 path and float64 for the "truth" used to rank fp32 implementations against each other.
