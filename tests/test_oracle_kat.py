@@ -127,3 +127,36 @@ def test_fp32_oracle_close_to_fp64(smpl_model):
     v64, j64, _ = O.SMPL(smpl_model, dtype=np.float64)(th[:, 75:], th[:, 3:75], get_skin=True)
     assert np.abs(v32 - v64).max() / np.abs(v64).max() < 5e-6
     assert np.abs(j32 - j64).max() / np.abs(j64).max() < 5e-6
+
+
+def test_rodrigues_matches_scipy_rotvec():
+    """independent implementation of the axis-angle map (scipy); the reference's 1e-8 quirk moves it by < 1e-7"""
+    from scipy.spatial.transform import Rotation
+
+    th = synthetic.make_thetas(32, seed=21)[:, 3:75].reshape(-1, 3).astype(np.float64)
+    R = O.batch_rodrigues(th)
+    np.testing.assert_allclose(R, Rotation.from_rotvec(th).as_matrix(), atol=2e-7)
+
+
+def test_fk_matches_direct_chain_product(smpl_model):
+    """batch_global_rigid_transformation against an explicit root-to-joint product of 4x4 matrices"""
+    g = np.random.Generator(np.random.Philox(22))
+    Rs = O.batch_rodrigues(g.normal(0, 0.5, (24, 3))).reshape(1, 24, 3, 3)
+    Js = g.normal(0, 0.3, (1, 24, 3))
+    par = smpl_model["kintree_table"][0].astype(np.int32)
+    newJ, A = O.batch_global_rigid_transformation(Rs, Js, par)
+    for j in (0, 5, 15, 23):
+        chain = []
+        k = j
+        while k >= 0:
+            chain.append(k)
+            k = par[k]
+        G = np.eye(4)
+        for k in reversed(chain):
+            T = np.eye(4)
+            T[:3, :3] = Rs[0, k]
+            T[:3, 3] = Js[0, k] - (Js[0, par[k]] if par[k] >= 0 else 0)
+            G = G @ T
+        np.testing.assert_allclose(newJ[0, j], G[:3, 3], atol=1e-12)
+        np.testing.assert_allclose(A[0, j, :3, :3], G[:3, :3], atol=1e-12)
+        np.testing.assert_allclose(A[0, j, :3, 3], G[:3, 3] - G[:3, :3] @ Js[0, j], atol=1e-12)
