@@ -160,3 +160,32 @@ def test_fk_matches_direct_chain_product(smpl_model):
         np.testing.assert_allclose(newJ[0, j], G[:3, 3], atol=1e-12)
         np.testing.assert_allclose(A[0, j, :3, :3], G[:3, :3], atol=1e-12)
         np.testing.assert_allclose(A[0, j, :3, 3], G[:3, 3] - G[:3, :3] @ Js[0, j], atol=1e-12)
+
+
+def test_lbs_matches_textbook_form(smpl_model):
+    """SMPL.__call__ against the textbook linear-blend-skinning sum  v' = sum_j w_j (G_j [v_posed - J_j; 0] + t_Gj)
+    written out per vertex (no relative-transform trick)."""
+    sm = O.SMPL(smpl_model, dtype=np.float64)
+    th = synthetic.make_thetas(2, seed=23).astype(np.float64)
+    verts, _, Rs = sm(th[:, 75:], th[:, 3:75], get_skin=True)
+    vt = smpl_model["v_template"].astype(np.float64)
+    sd = smpl_model["shapedirs"].astype(np.float64)
+    pd = smpl_model["posedirs"].astype(np.float64)
+    W = smpl_model["weights"].astype(np.float64)
+    Jr = smpl_model["J_regressor"].astype(np.float64)
+    par = smpl_model["kintree_table"][0].astype(np.int32)
+    for b in range(2):
+        v_shaped = vt + sd @ th[b, 75:]
+        J = Jr @ v_shaped
+        pf = (Rs[b, 1:] - np.eye(3)).reshape(207)
+        v_posed = v_shaped + pd @ pf
+        G = [None] * 24
+        for j in range(24):
+            T = np.eye(4)
+            T[:3, :3] = Rs[b, j]
+            T[:3, 3] = J[j] - (J[par[j]] if par[j] >= 0 else 0)
+            G[j] = T if par[j] < 0 else G[par[j]] @ T
+        out = np.zeros_like(vt)
+        for j in range(24):
+            out += W[:, j:j + 1] * ((v_posed - J[j]) @ G[j][:3, :3].T + G[j][:3, 3])
+        np.testing.assert_allclose(verts[b], out, atol=1e-10)
