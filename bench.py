@@ -26,6 +26,11 @@ import os
 import sys
 import time
 
+# The encoder runs its batch chunks on 3 HIP streams and RCCL adds streams of its own; the HIP runtime multiplexes all
+# streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and once two chunk streams share a queue
+# their overlap is lost (measured: 20.1 -> 18.4 ms/step with a process group alive).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -36,6 +41,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
 
 
 def main():
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)  # see the print at the end
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -85,7 +93,9 @@ def main():
     eng = pred.engine
     images = torch.from_numpy(synthetic.make_images(B, seed=1000 + rank)).cuda()
     want = eng.DEFAULT_OUTPUTS + (("verts2d",) if args.config5 else ())
-    run, outs = eng.make_forward_plan(B, all_stages=True, want=want)
+    # two output sets used alternately: the all-gather of step k reads theta_k while step k+1 already writes theta_{k+1}
+    plans = [eng.make_forward_plan(B, all_stages=True, want=want) for _ in range(2)]
+    run, outs = plans[0]
     if args.config5:
         from hpe_amd import distributed as D
         from hpe_amd.ops import kp_reprojection_loss
@@ -94,24 +104,44 @@ def main():
         seg_gts = torch.from_numpy(seg_np[..., 0].copy()).cuda()
         kp_gts = torch.from_numpy(kp_np).cuda()
         losses = {}
-    theta_all = torch.empty((world * B, 85), dtype=torch.float32, device="cuda") if use_dist else None
+    theta_all = [torch.empty((world * B, 85), dtype=torch.float32, device="cuda") for _ in range(2)] if use_dist else None
+    pending = [None, None]
+    step_no = [0]
 
     def step():
-        o = run(images)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if use_dist and pending[k] is not None:
+            pending[k].wait()  # the gather that last used this output set (two steps ago)
+            pending[k] = None
+        o = plans[k][0](images)
         if args.config5:
             kp, mr = [], []
             for st in o:
                 parts = kp_reprojection_loss(kp_gts, st["kp2d"], return_parts=True)
                 mesh = eng.mesh_loss(seg_gts, st["verts2d"])
-                k, m = D.reduce_losses(parts, mesh) if use_dist else (parts[2], mesh)
-                kp.append(60.0 * k)
-                mr.append(0.001 * m)
+                k5, m5 = D.reduce_losses(parts, mesh) if use_dist else (parts[2], mesh)
+                kp.append(60.0 * k5)
+                mr.append(0.001 * m5)
             losses["kpr"], losses["mr"] = kp, mr
         if use_dist:
-            dist.all_gather_into_tensor(theta_all, o[-1]["theta"])
+            # the ONE data-path collective: all-gather of the predicted theta over RCCL, asynchronous so that it overlaps
+            # the next batch's encoder (it is waited for before its buffers are reused and before the timed region ends)
+            pending[k] = dist.all_gather_into_tensor(theta_all[k], o[-1]["theta"], async_op=True)
         return o
 
+    # one-time initialisation that is not a benchmark step: code-object load / first-launch setup of every kernel and the RCCL
+    # communicator (both are lazy); the W warm-up steps and the K timed steps follow
+    eng.forward(images[:2], all_stages=True)
+    if use_dist:
+        dist.all_gather_into_tensor(theta_all[0], outs[-1]["theta"])
+    torch.cuda.synchronize()
+
     def fence():
+        for k in range(2):
+            if use_dist and pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -145,7 +175,7 @@ def main():
         #     53 launches; the sum matches the rocprofv3 --kernel-trace --stats durations (profiles/).
         eng.enable_timing(2)
         step()
-        torch.cuda.synchronize()
+        fence()
         ts = eng.timings()
         per_conv = eng.conv_timings()
         serial_tf = ENCODER_GFLOP_PER_IMG * B / ts["conv_ms"]
@@ -211,8 +241,9 @@ def main():
             "sample": "%d of the %d bench images, full path (ResNet-50 + 3 IEF stages + SMPL x3), CPU restatement of "
                       "the reference (NumPy + torch-CPU conv2d), not TensorFlow" % (n, B),
         }
-        j = outs[-1]["joints"][:n].cpu().numpy()
-        v = outs[-1]["verts"][:n].cpu().numpy()
+        last_outs = plans[(step_no[0] - 1) & 1][1]
+        j = last_outs[-1]["joints"][:n].cpu().numpy()
+        v = last_outs[-1]["verts"][:n].cpu().numpy()
         parity = {
             "mpjpe_vs_oracle": float(np.linalg.norm(j - ref["generated_joints"], axis=-1).mean()),
             "verts_rel_err": float(np.abs(v - ref["generated_verts"]).max() / np.abs(ref["generated_verts"]).max()),
@@ -249,10 +280,16 @@ def main():
             line["phase_ms"] = phase
         if parity:
             line["parity"] = parity
-        print(json.dumps(line))
+        # stdout carries exactly one line: native libraries (RCCL prints a version banner on fd 1 when its communicator is
+        # created) wrote to stderr for the whole run, the JSON goes to the real stdout
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         if rank == 0 and world == 1:
-            assert torch.equal(theta_all, outs[-1]["theta"]), "all-gather at world 1 must return the local theta"
+            last = (step_no[0] - 1) & 1
+            assert torch.equal(theta_all[last], plans[last][1][-1]["theta"]), "all-gather at world 1 must return the local theta"
         dist.destroy_process_group()
 
 

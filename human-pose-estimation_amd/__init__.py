@@ -5,7 +5,13 @@ Host side mirrors the reference's interface for this path: ``Predictor`` (src/pr
 ``kp_reprojection_loss`` / ``mesh_reprojection_loss`` (src/ops.py).  All arithmetic runs in the C-ABI
 library ``lib/libhpe_hip.so`` (include/hpe.h); there is no CPU fallback.
 """
-from . import resnet_spec, synthetic  # noqa: F401
+import os as _os
+
+# Batch-chunk streams + RCCL's own streams must not share hardware queues (DESIGN.md "Multi-GPU"); only effective when the
+# package is imported before the first HIP call of the process, which is the normal order.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import resnet_spec, synthetic  # noqa: F401,E402
 from ._lib import HpeError  # noqa: F401
 from .engine import HpeEngine  # noqa: F401
 from .image import get_original, preprocess_image  # noqa: F401
