@@ -27,35 +27,15 @@ import numpy as np
 from . import engine as _engine
 from .projection import batch_orth_proj_idrot
 from .smpl import SMPL
+from . import assets
 
 
 def _load_smpl_file(path):
-    if path.endswith(".npz"):
-        with np.load(path, allow_pickle=False) as z:
-            return {k: z[k] for k in z.files}
-    import pickle
-
-    with open(path, "rb") as f:  # the user's own licensed model.pkl (reference: batch_smpl.py:31-32)
-        try:
-            return pickle.load(f)
-        except UnicodeDecodeError:
-            f.seek(0)
-            return pickle.load(f, encoding="latin1")
+    return assets.load_smpl_model(path)  # allow-list unpickler / .npz (batch_smpl.py:31-81)
 
 
 def _load_mean_file(smpl_model_path):
-    base = join(dirname(smpl_model_path), "neutral_smpl_mean_params")
-    if os.path.exists(base + ".npz"):
-        with np.load(base + ".npz", allow_pickle=False) as z:
-            return {"pose": z["pose"], "shape": z["shape"]}
-    if os.path.exists(base + ".h5"):
-        try:
-            import h5py
-        except ImportError as e:  # pragma: no cover
-            raise ImportError("reading %s.h5 needs h5py; convert it to .npz with keys pose/shape" % base) from e
-        with h5py.File(base + ".h5", "r") as f:
-            return {"pose": np.array(f["pose"]), "shape": np.array(f["shape"])}
-    raise FileNotFoundError(base + ".{npz,h5}")
+    return assets.load_mean_params(smpl_model_path)  # .npz or the deepdish .h5 (predictor.py:93-95)
 
 
 class Predictor(object):
