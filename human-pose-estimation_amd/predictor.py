@@ -12,8 +12,9 @@ Differences, all deliberate:
   * any batch size <= ``config.batch_size`` works (the reference requires equality, F10); larger inputs are
     processed in chunks of ``config.batch_size``;
   * the renderer, optimizers and critic the reference instantiates as import/ctor side effects are dropped;
-  * assets come from ``config.smpl_model_path`` (a chumpy-free pickle or .npz with the SMPL keys) /
-    ``neutral_smpl_mean_params.{npz,h5}`` next to it / ``<checkpoint_dir>/weights.npz`` (Keras-layout names),
+  * assets come from ``config.smpl_model_path`` (the SMPL pickle, read by an allow-list unpickler, or .npz) /
+    ``neutral_smpl_mean_params.{npz,h5}`` next to it / ``<checkpoint_dir>``: ``weights.npz`` (Keras-layout names) or the
+    reference's own ``tf.train.Checkpoint`` files (``tf_checkpoint.py``, no TensorFlow needed),
     or are passed directly as dicts (``smpl_model=``, ``mean_params=``, ``encoder_params=``, ``regressor_params=``).
     Missing weights are an error here (the reference silently keeps random init when no checkpoint exists).
 """
@@ -77,15 +78,22 @@ class Predictor(object):
         self.mean_np = self.load_mean_param()
         self.engine.load_mean_theta(self.mean_np)
         # ---- networks (reference :73-86: restore feature_extractor / generator3d from the checkpoint)
+        w, self.checkpoint_info = None, None
         if encoder_params is None or regressor_params is None:
             w = getattr(config, "weights", None)
             if w is None and self.checkpoint_dir and os.path.exists(join(self.checkpoint_dir, "weights.npz")):
                 with np.load(join(self.checkpoint_dir, "weights.npz"), allow_pickle=False) as z:
                     w = {k: z[k] for k in z.files}
+            if w is None and self.checkpoint_dir and os.path.exists(join(self.checkpoint_dir, "checkpoint")):
+                # what the reference restores (:77-86): the newest tf.train.Checkpoint in checkpoint_dir, read without TF
+                from . import tf_checkpoint
+
+                w, self.checkpoint_info = tf_checkpoint.load_hmr_weights(self.checkpoint_dir)
             if w is None:
                 raise FileNotFoundError(
-                    "no encoder/regressor weights: pass encoder_params/regressor_params, config.weights, or put "
-                    "weights.npz (Keras-layout names) in config.checkpoint_dir"
+                    "no encoder/regressor weights: pass encoder_params/regressor_params, config.weights, or put a "
+                    "TensorFlow checkpoint (checkpoint + ckpt-N.index/.data-*) or weights.npz (Keras-layout names) in "
+                    "config.checkpoint_dir"
                 )
             encoder_params = encoder_params or w
             regressor_params = regressor_params or w
@@ -94,7 +102,10 @@ class Predictor(object):
         self.engine.finalize()
         self.smpl = SMPL(None, engine=self.engine)
         self.mean_var = torch.from_numpy(self.mean_np).to(self.engine.tdev)
+        # the reference tracks `theta_prev` in its checkpoint as "inital_theta" (:84) but predicts from `mean_var` (:126)
         self.theta_prev = self.mean_var
+        if w is not None and "inital_theta" in w:
+            self.theta_prev = torch.from_numpy(np.asarray(w["inital_theta"], np.float32)).to(self.engine.tdev)
 
     def load_mean_param(self):
         """reference: src/predictor.py:88-110 -- zeros(1,85); [0,0]=0.9; pose[:3]=0 then pose[0]=pi; shape."""

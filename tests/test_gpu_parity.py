@@ -4,6 +4,8 @@ compared with the CPU oracle on identical seeded inputs.
 Tolerance (BASELINE north_star: "within 1e-4 relative fp32"): rel(a, b) = max|a-b| / max|b| <= 1e-4 for
 verts / joints / kp2d / theta; single kernels are held to tighter bounds written at each assert.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -432,3 +434,49 @@ def test_predictor_from_files(tmp_path, assets):
 
     r2 = p.predict(torch.from_numpy(img))  # CPU torch tensor input is moved to the device
     np.testing.assert_array_equal(cpu(r2["theta"]), cpu(r["theta"]))
+
+
+def test_predictor_from_reference_file_formats(tmp_path, assets):
+    """Everything in the reference's own on-disk formats: SMPL model.pkl (scipy-sparse regressors), the deepdish/PyTables
+    style neutral_smpl_mean_params.h5 (written here by the committed h5py-made fixture's layout: see tests/golden/
+    make_hdf5_golden.py -- the fixture file itself is used), and a tf.train.Checkpoint directory (object-graph TensorBundle
+    from tests/tf_bundle_writer.py; parity with TF-written files is unpinned, see tf_checkpoint.py)."""
+    import pickle
+    import shutil
+
+    import scipy.sparse as sp
+
+    import tf_bundle_writer as W
+    from hpe_amd import tf_checkpoint as T
+    from test_tf_checkpoint import _hmr_tensors
+
+    m = assets["smpl"]
+    pkl = dict(m)
+    pkl["J_regressor"] = sp.csc_matrix(m["J_regressor"])
+    pkl["cocoplus_regressor"] = sp.csc_matrix(m["cocoplus_regressor"])
+    model_dir = tmp_path / "models"
+    model_dir.mkdir()
+    with open(model_dir / "model.pkl", "wb") as f:
+        pickle.dump(pkl, f, protocol=2)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hdf5")
+    shutil.copy(os.path.join(gold, "mean_params.h5"), model_dir / "neutral_smpl_mean_params.h5")
+    exp = np.load(os.path.join(gold, "expected.npz"), allow_pickle=False)
+    mean = {"pose": exp["mean_params.h5:/pose"], "shape": exp["mean_params.h5:/shape"]}
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    W.write_bundle(str(ckpt / "ckpt-5"), _hmr_tensors(assets["enc"], assets["reg"], T.keras_weighted_layer_order(False)))
+    W.write_checkpoint_state(str(ckpt), "ckpt-5")
+
+    class Cfg(object):
+        img_size, num_stage, batch_size = 224, 3, 2
+        smpl_model_path = str(model_dir / "model.pkl")
+        checkpoint_dir = str(ckpt)
+
+    p = hpe_amd.Predictor(Cfg())
+    assert "object graph" in p.checkpoint_info["resolved_by"] and tuple(p.theta_prev.shape) == (1, 85)
+    img = synthetic.make_images(2, seed=92)
+    r = p.predict(img)
+    mean_var = O.load_mean_param(mean)
+    ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], mean_var)
+    for k in ("generated_joints", "generated_verts", "generated_cams", "theta"):
+        assert rel(cpu(r[k]), ref[k]) < TOL, k
