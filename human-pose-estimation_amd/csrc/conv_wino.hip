@@ -1,0 +1,285 @@
+// conv_wino.hip -- 3x3 / stride 1 / SAME convolutions of the ResNet-50 bottlenecks (res*_branch2b, reference:
+// src/models.py:39 -> keras_applications resnet50 conv_block / identity_block) as Winograd F(2x2, 3x3) in fp32:
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, summed over input channels
+//
+// 16 multiplies per tile and channel pair instead of 36: the MFMA work of these 16 layers (48 % of the encoder's
+// FLOPs) shrinks 2.25x (1.72x on the 7x7 maps, whose 4x4 tile grid covers 8x8).  Arithmetic stays fp32 end to end.
+//
+// Two kernels per layer:
+//   wino_input_kernel   x [B,H,W,C] NHWC -> V, HBM bound (reads x once, writes 4x its size).  V is stored in the exact
+//                       byte image the GEMM kernel's LDS staging wants, so that each k-slab of a workgroup is one
+//                       contiguous 32 KB block:   V[tile block of 64][slab of 8 ch][comp 16][half 2][tile 64][4 ch]
+//   wino_gemm_kernel    16 independent GEMMs  M_c[tile][cout] = sum_ch V_c[tile][ch] * U_c[cout][ch]  for a 64-tile x
+//                       64-cout block, all 16 components in one workgroup (8 waves x 2 components x four 32x32 MFMA
+//                       blocks = 128 accumulator VGPRs per lane), LDS-DMA double buffering (2 x 64 KB), then the output
+//                       transform A^T M A through LDS, BN scale/shift, ReLU and 16 B/lane NHWC stores.
+//                       U = G g G^T is precomputed on the host in the same blocked layout.
+//
+// Why the input transform is not fused into the GEMM: a slab can only hold 8 channels of 64 tiles x 16 components
+// (LDS), i.e. 32 B of every 128 B activation line per pass, and the 1024 lines a workgroup touches per slab do not
+// survive in the 32 KB L1 until the next slab -> 4x L2 traffic.  The blocked V removes the problem at the price of one
+// extra HBM round trip that runs concurrently with another batch chunk's MFMA-bound GEMM (chunk streams).
+#include "hpe_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WT = 64;             // tiles per workgroup
+constexpr int WN_ = 64;            // output channels per workgroup
+constexpr int WK = 8;              // channels per slab
+constexpr int OPER = 16 * 2 * 64 * 4;  // floats of one operand (V or U) per slab = 8192 (32 KB)
+
+// ------------------------------------------------------------------------------------------------ input transform
+// one thread = (tile, 4 channels); a wave = 8 tiles x 32 channels (full 128-B lines on the read side, 128-B
+// segments on the write side)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C,
+                                                         int TW, int TT, int T, int Tpad, int lda) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = gid & 63;
+    const int wv = gid >> 6;
+    const int ncb = C >> 5;
+    const int tg = wv / ncb;
+    const int cb = wv - tg * ncb;
+    const int t = tg * 8 + (lane >> 3);
+    if (t >= Tpad) return;
+    const int c = cb * 32 + (lane & 7) * 4;
+    const int S = C >> 3;
+    float* dst = V + ((((size_t)(t >> 6) * S + (c >> 3)) * 16) * 2 + ((c >> 2) & 1)) * 256 + (t & 63) * 4;
+    if (t >= T) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(dst + k * 512) = z;
+        return;
+    }
+    const int b = t / TT;
+    const int rem = t - b * TT;
+    const int ty = rem / TW;
+    const int tx = rem - ty * TW;
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int iy = y0 + a;
+        const bool oky = iy >= 0 && iy < H;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ix = x0 + e;
+            const bool ok = oky && ix >= 0 && ix < W;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            d[a][e] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * lda + c) : z;
+        }
+    }
+    // B^T d (rows), then (.) B (columns);  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    f32x4 r[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[0][e] = d[0][e] - d[2][e];
+        r[1][e] = d[1][e] + d[2][e];
+        r[2][e] = d[2][e] - d[1][e];
+        r[3][e] = d[1][e] - d[3][e];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        *reinterpret_cast<f32x4*>(dst + (a * 4 + 0) * 512) = r[a][0] - r[a][2];
+        *reinterpret_cast<f32x4*>(dst + (a * 4 + 1) * 512) = r[a][1] + r[a][2];
+        *reinterpret_cast<f32x4*>(dst + (a * 4 + 2) * 512) = r[a][2] - r[a][1];
+        *reinterpret_cast<f32x4*>(dst + (a * 4 + 3) * 512) = r[a][1] - r[a][3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 16-component GEMM + output transform
+struct WinoArgs {
+    const float* V;
+    const float* U;
+    const float* scale;
+    const float* shift;
+    float* y;
+    int H, W, N;      // output map, output channels
+    int TW, TT, T;    // tiles per row / per image / total
+    int S;            // k-slabs (C / 8)
+    int n_tb, n_nt;   // tile blocks, cout blocks
+    int ldy, relu;
+};
+
+__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(WinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (V slab + U slab) = 128 KB; reused by the epilogue
+
+    const int total = p.n_tb * p.n_nt;
+    const int bid = blockIdx.x;
+    // XCD-aware bijective remap: consecutive logical ids (the cout blocks of one tile block) share an XCD and its L2
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tb = lid / p.n_nt;
+    const int nt = lid - tb * p.n_nt;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hi = lane >> 5;
+
+    const float* vsrc = p.V + (size_t)tb * p.S * OPER + wave * 1024 + lane * 4;
+    const float* usrc = p.U + (size_t)nt * p.S * OPER + wave * 1024 + lane * 4;
+
+    auto issue = [&](int s, int buf) {
+        float* dstv = lds + buf * (2 * OPER) + wave * 1024;
+        const float* sv = vsrc + (size_t)s * OPER;
+        const float* su = usrc + (size_t)s * OPER;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sv + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dstv + i * 256), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(su + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dstv + OPER + i * 256), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
+
+    // fragment offsets (floats) inside an operand slab: [comp][half][row][4]
+    const int frag = ((2 * wave) * 2 + hi) * 256 + (lane & 31) * 4;
+
+    issue(0, 0);
+    __syncthreads();
+    for (int s = 0; s < p.S; ++s) {
+        const int cur = (s & 1) * (2 * OPER);
+        if (s + 1 < p.S) issue(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&lds[cur + frag + c * 512 + i * 128]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&lds[cur + OPER + frag + c * 512 + j * 128]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[c][i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: M[comp][tile][cout] of one 32-tile half through LDS, output transform, BN, ReLU, NHWC stores
+    const int n0 = nt * WN_;
+    const int em = t >> 4;          // tile within the half
+    const int eq = (t & 15) * 4;    // cout quad
+    const int n = n0 + eq;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    lds[((2 * wave + c) * 32 + m) * 64 + 32 * j + (lane & 31)] = acc[c][i][j][e];
+                }
+        __syncthreads();
+        const int tg = tb * WT + 32 * i + em;
+        if (tg < p.T) {
+            f32x4 M[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) M[c] = *reinterpret_cast<const f32x4*>(&lds[(c * 32 + em) * 64 + eq]);
+            // A^T = [1 1 1 0; 0 1 -1 -1]
+            f32x4 u0[4], u1[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                u0[v] = M[v] + M[4 + v] + M[8 + v];
+                u1[v] = M[4 + v] - M[8 + v] - M[12 + v];
+            }
+            f32x4 o[2][2];
+            o[0][0] = u0[0] + u0[1] + u0[2];
+            o[0][1] = u0[1] - u0[2] - u0[3];
+            o[1][0] = u1[0] + u1[1] + u1[2];
+            o[1][1] = u1[1] - u1[2] - u1[3];
+            const int b = tg / p.TT;
+            const int rem = tg - b * p.TT;
+            const int ty = rem / p.TW;
+            const int tx = rem - ty * p.TW;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int oy = 2 * ty + dy, ox = 2 * tx + dx;
+                    if (oy < p.H && ox < p.W) {
+                        f32x4 v = o[dy][dx] * sc + sh;
+                        if (p.relu) {
+                            v.x = fmaxf(v.x, 0.f);
+                            v.y = fmaxf(v.y, 0.f);
+                            v.z = fmaxf(v.z, 0.f);
+                            v.w = fmaxf(v.w, 0.f);
+                        }
+                        *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace
+
+size_t hpe_wino_v_floats(int B, int H, int W, int C) {
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const size_t T = (size_t)B * TH * TW;
+    return ((T + 63) / 64) * 64 * 16 * (size_t)C;
+}
+
+hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy,
+                                 int B, int H, int W, int C, int N, int relu, float* V, hipStream_t st) {
+    if (C % 32 != 0 || N % 64 != 0 || lda % 4 != 0 || ldy % 4 != 0 || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    constexpr int LDS_BYTES = 2 * 2 * OPER * (int)sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2, TT = TH * TW;
+    const long Tl = (long)B * TT;
+    if (Tl > (1L << 30)) return hipErrorInvalidValue;
+    const int T = (int)Tl;
+    const int Tpad = (T + 63) / 64 * 64;
+    {
+        const long waves = (long)(Tpad / 8) * (C / 32);
+        const int blocks = (int)((waves + 3) / 4);
+        hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(256), 0, st, x, V, H, W, C, TW, TT, T, Tpad, lda);
+    }
+    WinoArgs p;
+    p.V = V;
+    p.U = U;
+    p.scale = scale;
+    p.shift = shift;
+    p.y = y;
+    p.H = H;
+    p.W = W;
+    p.N = N;
+    p.TW = TW;
+    p.TT = TT;
+    p.T = T;
+    p.S = C / 8;
+    p.n_tb = Tpad / 64;
+    p.n_nt = N / 64;
+    p.ldy = ldy;
+    p.relu = relu;
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(512), LDS_BYTES, st, p);
+    return hipGetLastError();
+}

@@ -86,6 +86,7 @@ struct ConvLayer {
     float* w = nullptr;  // device, packed [n_pad][k_pad] (fp32) or bf16 [n_pad][k_pad16] in bf16 mode
     float* scale = nullptr;
     float* shift = nullptr;
+    float* wino_u = nullptr;  // device, G g G^T in the blocked layout of conv_wino.hip (3x3 layers on the Winograd path only)
     int n_pad = 0, k_pad = 0;
 };
 
@@ -103,6 +104,11 @@ struct DenseLayer {
 constexpr int STEM_HP = 230;  // 224 + 2*3
 constexpr int STEM_WP = 232;  // 224 + 2*3 + 2 (8th tap column of the last window, zero weights)
 constexpr int THETA_LD = 96;  // theta rows padded to 3 k-slabs of 32
+// Winograd V workspace: image-major with this per-image pitch; a chunk of >= 32 images starting at image i0 owns
+// [i0 * pitch, (i0 + n) * pitch): n * 802816 floats of transformed tiles (16 * tiles * C <= 802816 per image for every
+// 3x3 layer) + up to 63 padding tiles * 16 * 512 = 516096 floats <= n * 16384
+constexpr size_t WINO_V_PITCH = 802816 + 16384;
+constexpr size_t WINO_V_SLACK = 524288;
 
 }  // namespace
 
@@ -138,6 +144,8 @@ struct hpe_ctx {
     float* partial = nullptr;  // split-K workspace (small grids only run unchunked on the caller's stream)
     size_t partial_floats = 0;
     int chunk_images = 0;
+    float* wino_v = nullptr;  // Winograd input-transform workspace (nullptr: direct convolution everywhere)
+    int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
     // timing
@@ -222,9 +230,12 @@ int pick_tile_bf16(int M, int N) {
     } while (0)
 
 // one conv layer (+BN fold, +residual, +ReLU) through the implicit-GEMM kernel
-hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st) {
+hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
+                    float* wino_v = nullptr) {
     const ConvSpec& s = specs()[idx];
     const ConvLayer& L = c->conv[idx];
+    if (L.wino_u && wino_v && !res)
+        return hpe_launch_wino_conv3(x, s.cin, L.wino_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st);
     GemmArgs p{};
     p.x = x;
     p.w = L.w;
@@ -295,10 +306,11 @@ hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const fl
     return hpe_launch_gemm(p, GEMM_DENSE, TILE_64x64, st);
 }
 
-hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st) {
+hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
+                      float* wino_v = nullptr) {
     const bool t2 = c->timing >= 2;
     if (t2) HIPE(hipEventRecord(c->cev0[idx], st));
-    HIPE(run_conv(c, idx, x, B, res, relu, y, st));
+    HIPE(run_conv(c, idx, x, B, res, relu, y, st, wino_v));
     if (t2) HIPE(hipEventRecord(c->cev1[idx], st));
     return hipSuccess;
 }
@@ -318,6 +330,8 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
     float* T2 = at(c->T2, o_mid);
     float* cur = at(c->X0, o_big);
     float* nxt = at(c->X1, o_big);
+    // the chunk's slice of the Winograd workspace (chunks of < 32 images only occur unchunked, i0 == 0: the slack at the end covers them)
+    float* wv = (c->wino_v && (i0 == 0 || B >= 32)) ? c->wino_v + (size_t)i0 * WINO_V_PITCH : nullptr;
     if (c->bf16) {
         HIPE(hpe_launch_pad_input_bf16(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
         HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
@@ -334,7 +348,7 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
             HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st));
-            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st));
+            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv));
             const float* res = cur;
             if (first) {
                 // projection shortcut (conv_block), no ReLU before the add
@@ -543,6 +557,10 @@ int hpe_finalize(hpe_ctx* c) {
     }
     DeviceGuard g(c->cfg.device);
     int rc;
+    {
+        const char* e = getenv("HPE_WINO_MINC");  // 0 disables the Winograd path
+        c->wino_min_c = e ? atoi(e) : 128;
+    }
     // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
     for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {
         const ConvSpec& s = specs()[i];
@@ -575,6 +593,27 @@ int hpe_finalize(hpe_ctx* c) {
                     for (int n = 0; n < s.cout; ++n) wt[(size_t)n * L.k_pad + k] = src[n];
                 }
         if ((rc = upload(c, &L.w, wt))) return rc;
+        if (c->wino_min_c > 0 && s.kh == 3 && s.stride == 1 && s.cin >= c->wino_min_c && s.cin % 32 == 0 && s.cout % 64 == 0) {
+            // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in double; layout [cout/64][cin/8][16][2][64][4]
+            static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const int S = s.cin / 8;
+            std::vector<float> U((size_t)16 * s.cin * s.cout);
+            for (int ci = 0; ci < s.cin; ++ci)
+                for (int n = 0; n < s.cout; ++n) {
+                    double g[3][3];
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) g[a][b] = L.kernel[(((size_t)a * 3 + b) * s.cin + ci) * s.cout + n];
+                    const size_t base = ((((size_t)(n >> 6) * S + (ci >> 3)) * 16) * 2 + ((ci >> 2) & 1)) * 256 + (size_t)(n & 63) * 4 + (ci & 3);
+                    for (int xi = 0; xi < 4; ++xi)
+                        for (int nu = 0; nu < 4; ++nu) {
+                            double u = 0.0;
+                            for (int a = 0; a < 3; ++a)
+                                for (int b = 0; b < 3; ++b) u += G[xi][a] * G[nu][b] * g[a][b];
+                            U[base + (size_t)(xi * 4 + nu) * 512] = (float)u;
+                        }
+                }
+            if ((rc = upload(c, &L.wino_u, U))) return rc;
+        }
         }
         std::vector<float> sc(s.cout), sh(s.cout);
         for (int n = 0; n < s.cout; ++n) {
@@ -678,6 +717,9 @@ int hpe_finalize(hpe_ctx* c) {
             if ((rc = dev_alloc(c, &c->T1, B * 200704, false))) return rc;
             if ((rc = dev_alloc(c, &c->T2, B * 200704, false))) return rc;
             if ((rc = dev_alloc(c, &c->feat, B * HPE_FEATURE_DIM, true))) return rc;
+        }
+        if (c->have_encoder && !c->bf16 && c->wino_min_c > 0) {
+            if ((rc = dev_alloc(c, &c->wino_v, B * WINO_V_PITCH + WINO_V_SLACK, false))) return rc;
         }
         {
             c->partial_floats = (size_t)512 * 128 * 128;  // 512 slices of the largest tile (32 MB)
@@ -886,7 +928,7 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
         HIP_TRY(hpe_launch_pad_input(x, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
         in = c->padded;
     }
-    HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st));
+    HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st, c->wino_v));
     return HPE_OK;
 }
 
