@@ -146,6 +146,7 @@ struct hpe_ctx {
     int chunk_images = 0;
     float* wino_v = nullptr;  // Winograd input-transform workspace (nullptr: direct convolution everywhere)
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
+    int wino_min_items = 128; // ... when the launch has at least this many workgroups
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
     // timing
@@ -234,7 +235,9 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
                     float* wino_v = nullptr) {
     const ConvSpec& s = specs()[idx];
     const ConvLayer& L = c->conv[idx];
-    if (L.wino_u && wino_v && !res)
+    // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
+    // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
+    if (L.wino_u && wino_v && !res && (long)((B * ((s.hin + 1) / 2) * ((s.hin + 1) / 2) + 63) / 64) * (s.cout / 64) >= c->wino_min_items)
         return hpe_launch_wino_conv3(x, s.cin, L.wino_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st);
     GemmArgs p{};
     p.x = x;
@@ -560,6 +563,8 @@ int hpe_finalize(hpe_ctx* c) {
     {
         const char* e = getenv("HPE_WINO_MINC");  // 0 disables the Winograd path
         c->wino_min_c = e ? atoi(e) : 128;
+        e = getenv("HPE_WINO_MIN_ITEMS");
+        c->wino_min_items = e ? atoi(e) : 128;
     }
     // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
     for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {

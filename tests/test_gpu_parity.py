@@ -146,6 +146,72 @@ def test_conv_layer_matches_oracle(engine, assets, name, B):
     assert rel(y, ref) < 5e-6, name
 
 
+@pytest.fixture(scope="module")
+def engines_direct_and_wino(assets):
+    """Two encoder-only contexts: every 3x3 layer direct (HPE_WINO_MINC=0) / Winograd for C >= 64 at any batch (the product
+    default is C >= 128 and >= 128 work items per launch; the environment is read once, in hpe_finalize)."""
+    made = []
+    for env in ({"HPE_WINO_MINC": "0"}, {"HPE_WINO_MINC": "64", "HPE_WINO_MIN_ITEMS": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = hpe_amd.HpeEngine(device=0, max_batch=40)
+            e.load_encoder(assets["enc"])
+            e.finalize()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        made.append(e)
+    yield made
+    for e in made:
+        e.close()
+
+
+WINO_CASES = ["res2b_branch2b", "res3a_branch2b", "res3d_branch2b", "res4c_branch2b", "res5a_branch2b", "res5c_branch2b"]
+
+
+@pytest.mark.parametrize("name", WINO_CASES)
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_winograd_conv_matches_oracle_and_direct(engines_direct_and_wino, assets, name, B):
+    """F(2x2,3x3) path against the fp64 oracle convolution and against the direct implicit-GEMM kernel: 56/28/14 maps tile
+    exactly, the 7x7 maps use a 4x4 tile grid with masked last row/column; B = 37 gives tile counts that are not a multiple of
+    the 64-tile workgroup block (zero-padded tiles, masked stores).  Input includes exact zeros and large values."""
+    direct, wino = engines_direct_and_wino
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    if B == 37 and s.hin > 28:
+        pytest.skip("oracle conv at this size is slow; covered by B = 3")
+    g = np.random.Generator(np.random.Philox(500 + idx + B))
+    x = g.normal(0, 1, (B, s.hin, s.hin, s.cin)).astype(np.float32)
+    x[g.random(x.shape) < 0.3] = 0.0  # post-ReLU sparsity
+    x[0, 0, 0, :] = 50.0  # a corner pixel: only 4 of the 9 taps see it
+    yw = cpu(wino.debug_conv(idx, gpu(x), relu=True))
+    yd = cpu(direct.debug_conv(idx, gpu(x), relu=True))
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    lin = O.conv2d_nhwc(x, p[s.name + "/kernel"], p[s.name + "/bias"], 1, 1, dtype=np.float64) * sc + sh
+    ref = np.maximum(lin, 0)
+    assert yw.shape == ref.shape
+    assert rel(yw, ref) < 5e-6 and rel(yd, ref) < 5e-6, (rel(yw, ref), rel(yd, ref))
+    assert rel(yw, yd) < 5e-6
+    # no ReLU, negative side preserved
+    assert rel(cpu(wino.debug_conv(idx, gpu(x), relu=False)), lin) < 5e-6
+
+
+def test_winograd_encoder_features_match_direct(engines_direct_and_wino, assets):
+    """Whole encoder, 40 images (2 batch chunks would need >= 64): features of the two contexts agree to fp32 round-off and
+    both match the oracle."""
+    direct, wino = engines_direct_and_wino
+    img = synthetic.make_images(5, seed=77)
+    fd, fw = cpu(direct.encoder(gpu(img))), cpu(wino.encoder(gpu(img)))
+    ref = O.resnet50_features(img, assets["enc"])
+    assert rel(fw, fd) < 2e-5
+    assert rel(fw, ref) < TOL and rel(fd, ref) < TOL
+
+
 def test_pools(engine):
     import ctypes as C
 

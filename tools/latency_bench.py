@@ -8,7 +8,7 @@ from oracle import hmr_oracle as O
 eng = hpe_amd.HpeEngine(device=0, max_batch=64)
 eng.load_smpl(synthetic.make_smpl_model()); eng.load_encoder(synthetic.make_encoder_params()); eng.load_regressor(synthetic.make_regressor_params())
 eng.load_mean_theta(O.load_mean_param(synthetic.make_mean_params())); eng.finalize()
-for B in (1, 8, 64):
+for B in (1, 8, 16, 32, 64):
     img = torch.from_numpy(synthetic.make_images(B, seed=B)).cuda()
     for graph in (False, True):
         run, outs = eng.make_forward_plan(B, graph=graph)
