@@ -102,27 +102,18 @@ struct WinoArgs {
     int S;            // k-slabs (C / 8)
     int n_tb, n_nt;   // tile blocks, cout blocks
     int ldy, relu;
+    // stream-K only
+    float* ws;            // [workgroups][128 accumulator floats x 512 threads]
+    unsigned* flags;      // [workgroups], holds the epoch of the launch that parked data
+    unsigned epoch;
 };
 
-__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(WinoArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (V slab + U slab) = 128 KB; reused by the epilogue
-
-    const int total = p.n_tb * p.n_nt;
-    const int bid = blockIdx.x;
-    // XCD-aware bijective remap: consecutive logical ids (the cout blocks of one tile block) share an XCD and its L2
-    const int xcd = bid & 7;
-    const int q = total >> 3, rr = total & 7;
-    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int tb = lid / p.n_nt;
-    const int nt = lid - tb * p.n_nt;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+// main loop over k-slabs [k0, k1) of work item (tb, nt); accumulators are added to (caller zeroes them)
+__device__ __forceinline__ void wino_mainloop(const WinoArgs& p, float* lds, int tb, int nt, int k0, int k1, f32x16 (&acc)[2][2][2], int wave,
+                                              int lane) {
     const int hi = lane >> 5;
-
-    const float* vsrc = p.V + (size_t)tb * p.S * OPER + wave * 1024 + lane * 4;
-    const float* usrc = p.U + (size_t)nt * p.S * OPER + wave * 1024 + lane * 4;
+    const float* vsrc = p.V + ((size_t)tb * p.S + k0) * OPER + wave * 1024 + lane * 4;
+    const float* usrc = p.U + ((size_t)nt * p.S + k0) * OPER + wave * 1024 + lane * 4;
 
     auto issue = [&](int s, int buf) {
         float* dstv = lds + buf * (2 * OPER) + wave * 1024;
@@ -138,24 +129,15 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(WinoArgs p) {
                                              (__attribute__((address_space(3))) void*)(dstv + OPER + i * 256), 16, 0, 0);
     };
 
-    f32x16 acc[2][2][2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
-
     // fragment offsets (floats) inside an operand slab: [comp][half][row][4]
     const int frag = ((2 * wave) * 2 + hi) * 256 + (lane & 31) * 4;
+    const int n = k1 - k0;
 
     issue(0, 0);
     __syncthreads();
-    for (int s = 0; s < p.S; ++s) {
+    for (int s = 0; s < n; ++s) {
         const int cur = (s & 1) * (2 * OPER);
-        if (s + 1 < p.S) issue(s + 1, (s + 1) & 1);
+        if (s + 1 < n) issue(s + 1, (s + 1) & 1);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 fa[2], fb[2];
@@ -173,8 +155,13 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(WinoArgs p) {
         }
         __syncthreads();
     }
+}
 
-    // ---- epilogue: M[comp][tile][cout] of one 32-tile half through LDS, output transform, BN, ReLU, NHWC stores
+// epilogue: M[comp][tile][cout] of one 32-tile half through LDS, output transform, BN, ReLU, NHWC stores.
+// Entered with all waves past the main loop's last barrier (LDS free); leaves with a barrier pending only for readers of
+// the second half, so the caller must __syncthreads() before the next LDS write.
+__device__ __forceinline__ void wino_epilogue(const WinoArgs& p, float* lds, int tb, int nt, f32x16 (&acc)[2][2][2], int t, int wave, int lane) {
+    const int hi = lane >> 5;
     const int n0 = nt * WN_;
     const int em = t >> 4;          // tile within the half
     const int eq = (t & 15) * 4;    // cout quad
@@ -235,6 +222,138 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(WinoArgs p) {
     }
 }
 
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2][2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
+}
+
+// one work item (64 tiles x 64 couts, all k-slabs) per workgroup: launches that cannot fill the persistent grid
+__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(WinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (V slab + U slab) = 128 KB; reused by the epilogue
+
+    const int total = p.n_tb * p.n_nt;
+    const int bid = blockIdx.x;
+    // XCD-aware bijective remap: consecutive logical ids (the cout blocks of one tile block) share an XCD and its L2
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tb = lid / p.n_nt;
+    const int nt = lid - tb * p.n_nt;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    f32x16 acc[2][2][2];
+    zero_acc(acc);
+    wino_mainloop(p, lds, tb, nt, 0, p.S, acc, wave, lane);
+    wino_epilogue(p, lds, tb, nt, acc, t, wave, lane);
+}
+
+// Persistent stream-K variant: one workgroup per CU.  Workgroups form teams of n_nt members (member j computes cout block j,
+// so a team streams each V block once through the XCD's L2 while its members read it concurrently); a team walks a
+// contiguous range of (tile block, k-slab) units of equal length for every team, so there is no partial last round of
+// workgroups.  A tile block cut by a range boundary is computed in two parts: the next team does slabs [k, S) as the FIRST
+// thing in its life and parks the raw accumulators in `ws`; this team reaches slabs [0, k) LAST, adds the parked part and
+// runs the epilogue -- the flag it polls was normally set long before.  The XCD L2s are not coherent with each other, so
+// the parked accumulators and the flag move with relaxed agent-scope atomics (sc1 accesses, coherent by themselves).
+__global__ __launch_bounds__(512, 2) void wino_gemm_streamk_kernel(WinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    const int nwg = gridDim.x;                   // multiple of 8 * n_nt
+    const int per_xcd = nwg >> 3;
+    const int lid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // teams are contiguous inside an XCD
+    const int team = lid / p.n_nt;
+    const int nt = lid - team * p.n_nt;
+    const int n_teams = nwg / p.n_nt;
+    const long units = (long)p.n_tb * p.S;
+    long u = units * team / n_teams;
+    const long u_end = units * (team + 1) / n_teams;
+
+    // A team's range is [tail part of a cut tile block][whole tile blocks ...][head part of a cut tile block]; the three kinds
+    // are separate code regions (one generic loop body makes the register allocator spill the 128 accumulators).
+    const int S = p.S;
+    int tb = (int)(u / S);
+    const int k_first = (int)(u - (long)tb * S);
+    if (k_first > 0) {
+        // tail part [k_first, S) of a tile block owned by the previous team: park the accumulators, publish
+        f32x16 acc[2][2][2];
+        zero_acc(acc);
+        wino_mainloop(p, lds, tb, nt, k_first, S, acc, wave, lane);
+        // parked data moves with relaxed AGENT-scope atomics (8 B each: sc1 stores / loads that are coherent at device level by
+        // themselves).  A release/acquire fence pair would do it too, but on a multi-XCD part it writes back / invalidates the
+        // whole L2 of the XCD -- measured +0.1 ms per layer because every workgroup's V/U reuse is lost with it.
+        unsigned long long* my_ws = reinterpret_cast<unsigned long long*>(p.ws) + (size_t)lid * (64 * 512) + t;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qd = 0; qd < 8; ++qd) {
+                        const unsigned long long v = (unsigned long long)__float_as_uint(acc[c][i][j][2 * qd]) |
+                                                     ((unsigned long long)__float_as_uint(acc[c][i][j][2 * qd + 1]) << 32);
+                        __hip_atomic_store(&my_ws[(((c * 2 + i) * 2 + j) * 8 + qd) * 512], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): this wave's stores are acknowledged
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(p.flags + lid, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u += S - k_first;
+        ++tb;
+    }
+    const int tb_whole_end = (int)(u_end / S);  // whole tile blocks: [tb, tb_whole_end)
+    for (; tb < tb_whole_end; ++tb) {
+        f32x16 acc[2][2][2];
+        zero_acc(acc);
+        wino_mainloop(p, lds, tb, nt, 0, S, acc, wave, lane);
+        wino_epilogue(p, lds, tb, nt, acc, t, wave, lane);
+        __syncthreads();  // epilogue readers done before the next item's DMA lands in LDS
+    }
+    const int k_last = (int)(u_end - (long)tb_whole_end * S);
+    if (k_last > 0) {
+        // head part [0, k_last): the next team's member nt parked slabs [k_last, S) at the very start of its life
+        f32x16 acc[2][2][2];
+        zero_acc(acc);
+        wino_mainloop(p, lds, tb_whole_end, nt, 0, k_last, acc, wave, lane);
+        const int partner = lid + p.n_nt;
+        if (t == 0) {
+            // bounded (~1 s): every workgroup reaches its publish before anything it waits for, so the bound is never hit;
+            // it only keeps a logic error from hanging the device (the results would then fail parity)
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (__hip_atomic_load(p.flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.ws) + (size_t)partner * (64 * 512) + t;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    asm volatile("" ::: "memory");  // at most one 32x32 block (8 x 8 B per lane) of parked data in flight
+#pragma unroll
+                    for (int qd = 0; qd < 8; ++qd) {
+                        const unsigned long long v = __hip_atomic_load(&src[(((c * 2 + i) * 2 + j) * 8 + qd) * 512], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[c][i][j][2 * qd] += __uint_as_float((unsigned)(v & 0xFFFFFFFFull));
+                        acc[c][i][j][2 * qd + 1] += __uint_as_float((unsigned)(v >> 32));
+                    }
+                }
+        wino_epilogue(p, lds, tb_whole_end, nt, acc, t, wave, lane);
+    }
+}
+
 }  // namespace
 
 size_t hpe_wino_v_floats(int B, int H, int W, int C) {
@@ -244,12 +363,14 @@ size_t hpe_wino_v_floats(int B, int H, int W, int C) {
 }
 
 hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy,
-                                 int B, int H, int W, int C, int N, int relu, float* V, hipStream_t st) {
+                                 int B, int H, int W, int C, int N, int relu, float* V, const WinoStreamK* sk, hipStream_t st) {
     if (C % 32 != 0 || N % 64 != 0 || lda % 4 != 0 || ldy % 4 != 0 || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
     static bool attr_set = false;
     constexpr int LDS_BYTES = 2 * 2 * OPER * (int)sizeof(float);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_streamk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -263,7 +384,7 @@ hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const 
         const int blocks = (int)((waves + 3) / 4);
         hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(256), 0, st, x, V, H, W, C, TW, TT, T, Tpad, lda);
     }
-    WinoArgs p;
+    WinoArgs p{};
     p.V = V;
     p.U = U;
     p.scale = scale;
@@ -280,6 +401,14 @@ hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const 
     p.n_nt = N / 64;
     p.ldy = ldy;
     p.relu = relu;
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(512), LDS_BYTES, st, p);
+    // persistent stream-K grid: one workgroup per CU in teams of n_nt, every team at least one whole tile block
+    if (sk && sk->ws && sk->flags && sk->n_wg >= 8 && sk->n_wg % (8 * p.n_nt) == 0 && p.n_tb >= sk->n_wg / p.n_nt) {
+        p.ws = sk->ws;
+        p.flags = sk->flags;
+        p.epoch = sk->epoch;
+        hipLaunchKernelGGL(wino_gemm_streamk_kernel, dim3(sk->n_wg), dim3(512), LDS_BYTES, st, p);
+    } else {
+        hipLaunchKernelGGL(wino_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(512), LDS_BYTES, st, p);
+    }
     return hipGetLastError();
 }

@@ -145,6 +145,10 @@ struct hpe_ctx {
     size_t partial_floats = 0;
     int chunk_images = 0;
     float* wino_v = nullptr;  // Winograd input-transform workspace (nullptr: direct convolution everywhere)
+    float* wino_ws = nullptr;       // stream-K parking space, one slot of n_cu workgroups per chunk stream (nullptr: plain grid)
+    unsigned* wino_flags = nullptr;
+    unsigned wino_epoch = 0;
+    int n_cu = 0;
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     int wino_min_items = 128; // ... when the launch has at least this many workgroups
     hipStream_t aux[3]{};
@@ -232,13 +236,24 @@ int pick_tile_bf16(int M, int N) {
 
 // one conv layer (+BN fold, +residual, +ReLU) through the implicit-GEMM kernel
 hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
-                    float* wino_v = nullptr) {
+                    float* wino_v = nullptr, int slot = 0) {
     const ConvSpec& s = specs()[idx];
     const ConvLayer& L = c->conv[idx];
     // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
     // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
     if (L.wino_u && wino_v && !res && (long)((B * ((s.hin + 1) / 2) * ((s.hin + 1) / 2) + 63) / 64) * (s.cout / 64) >= c->wino_min_items)
-        return hpe_launch_wino_conv3(x, s.cin, L.wino_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st);
+    {
+        WinoStreamK sk{};
+        if (c->wino_ws && slot >= 0 && slot < 4) {
+            sk.ws = c->wino_ws + (size_t)slot * c->n_cu * HPE_WINO_WS_FLOATS;
+            sk.flags = c->wino_flags + (size_t)slot * c->n_cu;
+            sk.epoch = ++c->wino_epoch;
+            if (sk.epoch == 0) sk.epoch = ++c->wino_epoch;
+            sk.n_wg = c->n_cu;
+        }
+        return hpe_launch_wino_conv3(x, s.cin, L.wino_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v,
+                                     c->wino_ws ? &sk : nullptr, st);
+    }
     GemmArgs p{};
     p.x = x;
     p.w = L.w;
@@ -310,16 +325,16 @@ hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const fl
 }
 
 hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
-                      float* wino_v = nullptr) {
+                      float* wino_v = nullptr, int slot = 0) {
     const bool t2 = c->timing >= 2;
     if (t2) HIPE(hipEventRecord(c->cev0[idx], st));
-    HIPE(run_conv(c, idx, x, B, res, relu, y, st, wino_v));
+    HIPE(run_conv(c, idx, x, B, res, relu, y, st, wino_v, slot));
     if (t2) HIPE(hipEventRecord(c->cev1[idx], st));
     return hipSuccess;
 }
 
 // the encoder on images [i0, i0+B) of the batch (all workspace buffers are image-major)
-hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* features, int ldfeat, hipStream_t st) {
+hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* features, int ldfeat, hipStream_t st, int slot = 0) {
     // all workspace buffers are image-major; in bf16 mode the same allocations hold bf16 elements (half the bytes)
     const int esz = c->bf16 ? 2 : 4;
     auto at = [&](float* base, size_t elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elems * esz); };
@@ -351,7 +366,7 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
             HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st));
-            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv));
+            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot));
             const float* res = cur;
             if (first) {
                 // projection shortcut (conv_block), no ReLU before the add
@@ -388,7 +403,7 @@ hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features,
         const int n = (i0 + per <= B) ? per : (B - i0);
         const int sid = k % nstream;
         hipStream_t s = (sid == 0) ? st : c->aux[sid - 1];
-        HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s));
+        HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s, sid));
     }
     for (int k = 1; k < nstream; ++k) {
         HIPE(hipEventRecord(c->ev_join[k - 1], c->aux[k - 1]));
@@ -725,6 +740,19 @@ int hpe_finalize(hpe_ctx* c) {
         }
         if (c->have_encoder && !c->bf16 && c->wino_min_c > 0) {
             if ((rc = dev_alloc(c, &c->wino_v, B * WINO_V_PITCH + WINO_V_SLACK, false))) return rc;
+            // persistent stream-K scheduling of the Winograd GEMM: opt-in.  It removes the partial last round of workgroups
+            // (-7 % on a res4 layer, -2 % on the step with HPE_STREAMS=1) but with the default batch-chunk streams, whose
+            // kernels already fill those idle CUs, the step time is unchanged within noise (profiles/r01/g_wino_streamk.txt)
+            const char* e = getenv("HPE_WINO_STREAMK");
+            if (e && atoi(e) != 0) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, c->cfg.device));
+                c->n_cu = prop.multiProcessorCount;
+                if ((rc = dev_alloc(c, &c->wino_ws, (size_t)4 * c->n_cu * HPE_WINO_WS_FLOATS, false))) return rc;
+                float* fl = nullptr;
+                if ((rc = dev_alloc(c, &fl, (size_t)4 * c->n_cu, true))) return rc;
+                c->wino_flags = reinterpret_cast<unsigned*>(fl);
+            }
         }
         {
             c->partial_floats = (size_t)512 * 128 * 128;  // 512 slices of the largest tile (32 MB)

@@ -31,8 +31,17 @@ hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st);
 // conv_wino.hip: 3x3/s1 SAME convolution as Winograd F(2x2,3x3); U = G g G^T blocked [N/64][C/8][16][2][64][4], V workspace of
 // hpe_wino_v_floats(B, H, W, C) floats; C % 32 == 0, N % 64 == 0
 size_t hpe_wino_v_floats(int B, int H, int W, int C);
+// optional persistent stream-K scheduling of the GEMM: n_wg workgroups (one per CU), ws = n_wg * HPE_WINO_WS_FLOATS floats and
+// flags = n_wg zero-initialised words owned by the launching stream, epoch unique per launch (never 0)
+#define HPE_WINO_WS_FLOATS 65536
+struct WinoStreamK {
+    float* ws;
+    unsigned* flags;
+    unsigned epoch;
+    int n_wg;
+};
 hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy,
-                                 int B, int H, int W, int C, int N, int relu, float* V, hipStream_t st);
+                                 int B, int H, int W, int C, int N, int relu, float* V, const WinoStreamK* sk, hipStream_t st);
 
 // conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st);

@@ -212,6 +212,40 @@ def test_winograd_encoder_features_match_direct(engines_direct_and_wino, assets)
     assert rel(fw, ref) < TOL and rel(fd, ref) < TOL
 
 
+def test_winograd_streamk_matches_direct(assets):
+    """Opt-in persistent stream-K scheduling (HPE_WINO_STREAMK=1): at B = 90 nearly every workgroup of the res4 launch (69 tile
+    blocks on 64 teams) and half of the res3 launch (276 on 128) computes a cut tile block in two parts that meet through the
+    parked accumulators; results must equal the direct kernel's to fp32 round-off."""
+    B = 90
+    outs = []
+    for env in ({"HPE_WINO_MINC": "0"}, {"HPE_WINO_STREAMK": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = hpe_amd.HpeEngine(device=0, max_batch=B)
+            e.load_encoder(assets["enc"])
+            e.finalize()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        ys = []
+        for name in ("res3c_branch2b", "res4e_branch2b"):
+            idx = resnet_spec.CONV_INDEX[name]
+            s = resnet_spec.CONV_SPECS[idx]
+            g = np.random.Generator(np.random.Philox(900 + idx))
+            x = np.maximum(g.normal(0, 1, (B, s.hin, s.hin, s.cin)), 0).astype(np.float32)
+            for _ in range(3):  # repeated launches: a new epoch each time on the same flags
+                y = e.debug_conv(idx, gpu(x), relu=True)
+            ys.append(cpu(y))
+        outs.append(ys)
+        e.close()
+    for yd, yw in zip(*outs):
+        assert rel(yw, yd) < 5e-6
+
+
 def test_pools(engine):
     import ctypes as C
 
