@@ -350,6 +350,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_streamk_kernel(WinoArgs p) {
                         acc[c][i][j][2 * qd + 1] += __uint_as_float((unsigned)(v >> 32));
                     }
                 }
+        // consumed: clear the flag, so that a replay of this very launch (hipGraph: same epoch baked in) waits for fresh data
+        if (t == 0) __hip_atomic_store(p.flags + partner, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wino_epilogue(p, lds, tb_whole_end, nt, acc, t, wave, lane);
     }
 }
