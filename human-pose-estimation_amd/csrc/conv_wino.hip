@@ -12,7 +12,8 @@
 //                       contiguous 32 KB block:   V[tile block of 64][slab of 8 ch][comp 16][half 2][tile 64][4 ch]
 //   wino_gemm_kernel    16 independent GEMMs  M_c[tile][cout] = sum_ch V_c[tile][ch] * U_c[cout][ch]  for a 64-tile x
 //                       64-cout block, all 16 components in one workgroup (8 waves x 2 components x four 32x32 MFMA
-//                       blocks = 128 accumulator VGPRs per lane), LDS-DMA double buffering (2 x 64 KB), then the output
+//                       blocks = 128 accumulator VGPRs per lane), LDS-DMA double buffering (2 x 64 KB, two slabs in flight,
+//                       the barrier in the middle of a slab's MFMA work), then the output
 //                       transform A^T M A through LDS, BN scale/shift, ReLU and 16 B/lane NHWC stores.
 //                       U = G g G^T is precomputed on the host in the same blocked layout.
 //
@@ -133,28 +134,47 @@ __device__ __forceinline__ void wino_mainloop(const WinoArgs& p, float* lds, int
     const int frag = ((2 * wave) * 2 + hi) * 256 + (lane & 31) * 4;
     const int n = k1 - k0;
 
+    // Two slabs in flight.  Per slab s: [MFMAs of component 0] [barrier] [DMA of slab s+2 into the buffer slab s just vacated]
+    // [MFMAs of component 1].  The barrier sits in the middle of the MFMA work, after this wave has pulled both components'
+    // fragments of slab s into registers, so (a) every wave is done reading buffer s&1 when the DMA of slab s+2 overwrites it
+    // and (b) that DMA has a whole slab of MFMA time (16 + 16 MFMAs) to land before barrier s+1 waits for it.
     issue(0, 0);
-    __syncthreads();
+    if (n > 1) issue(1, 1);
+    if (n > 1)
+        __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): slab 0 landed, slab 1 (the 8 newest DMA instructions) may be in flight
+    else
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
     for (int s = 0; s < n; ++s) {
         const int cur = (s & 1) * (2 * OPER);
-        if (s + 1 < n) issue(s + 1, (s + 1) & 1);
+        f32x4 fa[2][2], fb[2][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            f32x4 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&lds[cur + frag + c * 512 + i * 128]);
+            for (int i = 0; i < 2; ++i) fa[c][i] = *reinterpret_cast<const f32x4*>(&lds[cur + frag + c * 512 + i * 128]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&lds[cur + OPER + frag + c * 512 + j * 128]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[c][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[c][i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) fb[c][j] = *reinterpret_cast<const f32x4*>(&lds[cur + OPER + frag + c * 512 + j * 128]);
         }
-        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][i][ks], fb[0][j][ks], acc[0][i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // lgkmcnt(0): my fragments of slab s are in registers; vmcnt(0): my part of slab s+1 has landed
+        if (s + 2 < n) issue(s + 2, s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][i][ks], fb[1][j][ks], acc[1][i][j], 0, 0, 0);
     }
+    __syncthreads();  // all waves out of the last slab before the epilogue reuses the LDS
 }
 
 // epilogue: M[comp][tile][cout] of one 32-tile half through LDS, output transform, BN, ReLU, NHWC stores.
