@@ -54,11 +54,29 @@ class _Reader:
         self.take(n)
 
 
+def _guard(fn):
+    """Anything a damaged file can provoke below (bad UTF-8 in a name, a corrupt deflate stream, absurd shapes, indices past the
+    end ...) surfaces as Hdf5Error, never as a stray exception type."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except Hdf5Error:
+            raise
+        except (ValueError, IndexError, KeyError, OverflowError, MemoryError, UnicodeError, zlib.error, RecursionError) as e:
+            raise Hdf5Error("corrupt HDF5 structure: %s: %s" % (type(e).__name__, e)) from e
+
+    return wrapped
+
+
 class Dataset:
     def __init__(self, f, name, shape, dtype, layout, filters):
         self._f, self.name, self.shape, self.dtype = f, name, shape, dtype
         self._layout, self._filters = layout, filters
 
+    @_guard
     def read(self):
         return self._f._read_dataset(self)
 
@@ -85,6 +103,7 @@ class Group(dict):
 
 
 class File:
+    @_guard
     def __init__(self, path_or_bytes):
         if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
             self.buf = bytes(path_or_bytes)
@@ -190,7 +209,11 @@ class File:
         size0 = r.u(1 << (flags & 3))
         blocks = [(r.pos, size0)]
         del start
+        n_blocks = 0
         while blocks:
+            n_blocks += 1
+            if n_blocks > 4096:
+                raise Hdf5Error("object header continuation chain too long (cyclic?)")
             pos, size = blocks.pop(0)
             br = _Reader(self.buf, pos)
             end = pos + size
@@ -435,8 +458,12 @@ class File:
         return raw
 
     def _read_dataset(self, ds):
-        n = int(np.prod(ds.shape, dtype=np.int64)) if ds.shape else 1
+        n = 1
+        for d in ds.shape:
+            n *= int(d)  # Python ints: no silent wrap-around on absurd dimensions
         nbytes = n * ds.dtype.itemsize
+        if nbytes > 1000 * len(self.buf) + (1 << 20):
+            raise Hdf5Error("%s: dataspace of %d bytes is implausible for a %d-byte file" % (ds.name, nbytes, len(self.buf)))
         kind = ds._layout[0]
         if kind == "compact":
             raw = ds._layout[1]

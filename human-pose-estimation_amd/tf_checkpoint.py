@@ -50,6 +50,23 @@ class CheckpointError(ValueError):
     pass
 
 
+def _guard(fn):
+    """A damaged index (bad UTF-8 in a key, a field with the wrong wire type, lengths past the end ...) surfaces as
+    CheckpointError, never as a stray exception type."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except (CheckpointError, FileNotFoundError, KeyError):
+            raise
+        except (ValueError, TypeError, IndexError, OverflowError, MemoryError, UnicodeError) as e:
+            raise CheckpointError("corrupt checkpoint structure: %s: %s" % (type(e).__name__, e)) from e
+
+    return wrapped
+
+
 # ----------------------------------------------------------------------------------------------- CRC-32C (Castagnoli)
 def _crc_table():
     t = np.zeros(256, dtype=np.uint32)
@@ -289,6 +306,7 @@ class _Entry:
 class BundleReader:
     """``BundleReader(prefix)`` -- prefix as given to ``Checkpoint.save`` (``.../ckpt-7``)."""
 
+    @_guard
     def __init__(self, prefix, verify=True):
         self.prefix = str(prefix)
         self.verify = verify
@@ -370,6 +388,7 @@ class BundleReader:
             raise CheckpointError("%s: tensor checksum mismatch" % key)
         return e, raw
 
+    @_guard
     def get(self, key):
         e, raw = self._raw(key)
         if e.dtype == DT_STRING:
@@ -417,6 +436,7 @@ def latest_checkpoint(checkpoint_dir, latest_filename="checkpoint"):
 class ObjectGraph:
     """nodes[i] = {'children': {local_name: node_id}, 'attributes': [(name, full_name, checkpoint_key)]}"""
 
+    @_guard
     def __init__(self, blob):
         self.nodes = []
         for fn, _wt, val in _proto_fields(blob):

@@ -91,3 +91,19 @@ def test_user_block_offset():
     shifted = b"\0" * 512 + raw  # superblock search at 512; addresses relative to it
     a, b = H.load(raw), H.load(shifted)
     assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["shape"], b["shape"])
+
+
+def test_byte_flips_never_escape_as_other_exceptions():
+    """Robustness: random damage either still parses or raises Hdf5Error -- nothing else (bad UTF-8 names, corrupt deflate
+    streams, absurd dimensions, out-of-range addresses)."""
+    rng = np.random.default_rng(7)
+    for fname, rounds in (("mean_params.h5", 1500), ("layouts.h5", 600)):
+        raw = open(os.path.join(GOLD, fname), "rb").read()
+        for _ in range(rounds):
+            b = bytearray(raw)
+            for _k in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            try:
+                H.load(bytes(b))
+            except H.Hdf5Error:
+                pass

@@ -164,3 +164,27 @@ def test_wrong_architecture_is_rejected(tmp_path, params):
     W.write_bundle(str(tmp_path / "ckpt-1"), _hmr_tensors(enc, reg, T.keras_weighted_layer_order(False)))
     with pytest.raises(T.CheckpointError, match="res4c_branch2b"):
         T.load_hmr_weights(str(tmp_path / "ckpt-1"))
+
+
+def test_byte_flips_in_the_index_never_escape_as_other_exceptions(tmp_path):
+    rng = np.random.default_rng(5)
+    tensors = {"a/b" + SUF: rng.normal(size=(3, 4)).astype(np.float32), "s": b"hello",
+               T.OBJECT_GRAPH_KEY: W.object_graph({"x": {"y": ("n", "a/b" + SUF)}})}
+    for i in range(60):
+        tensors["k/%03d" % i] = np.full((i % 3 + 1,), i, np.int32)
+    W.write_bundle(str(tmp_path / "x"), tensors)
+    idx = open(tmp_path / "x.index", "rb").read()
+    os.link(tmp_path / "x.data-00000-of-00001", tmp_path / "y.data-00000-of-00001")
+    for it in range(600):
+        b = bytearray(idx)
+        for _k in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        open(tmp_path / "y.index", "wb").write(b)
+        try:
+            rd = T.BundleReader(str(tmp_path / "y"), verify=bool(it & 1))  # without CRC checks damage reaches the parsers
+            for k in rd.keys():
+                rd.get(k)
+            if T.OBJECT_GRAPH_KEY in rd:
+                T.ObjectGraph(rd.get(T.OBJECT_GRAPH_KEY))
+        except (T.CheckpointError, FileNotFoundError):
+            pass
