@@ -144,7 +144,9 @@ __device__ __forceinline__ void wino_mainloop(const WinoArgs& p, float* lds, int
         __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8): slab 0 landed, slab 1 (the 8 newest DMA instructions) may be in flight
     else
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    asm volatile("" ::: "memory");  // no LDS access of the loop may be scheduled above this barrier
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     for (int s = 0; s < n; ++s) {
         const int cur = (s & 1) * (2 * OPER);
         f32x4 fa[2][2], fb[2][2];
