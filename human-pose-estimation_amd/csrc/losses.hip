@@ -8,6 +8,7 @@
 // The squared distance is evaluated in the reference's expanded form ((-2 a.b) + |a|^2) + |b|^2 in fp32 and
 // ties keep the lowest index (tf.argmin), so the chosen neighbours follow the reference's choice.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "hpe_internal.h"
 
@@ -129,6 +130,124 @@ __global__ __launch_bounds__(256) void nn_a2b_kernel(const float* __restrict__ p
     for (int u = 0; u < NN_PT; ++u) {
         const int idx = base + u * 256 + (int)threadIdx.x;
         if (idx < cnt) contrib += fabsf(ax[u] - cx[u]) + fabsf(ay[u] - cy[u]);
+    }
+    const float s = block_sum_256(contrib, red);
+    if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = s;
+}
+
+// A -> B on the matrix cores.  The reference forms D = -2 A B^T + |A|^2 + |B|^2 with a matmul (src/ops.py:60-71) and takes
+// argmin over B.  |A|^2 is constant per point, so the search minimises  |b|^2 - 2 a.b,  which is exactly one
+// v_mfma_f32_32x32x2_f32 per 32 vertices x 32 points: A operand (-2 bx | -2 by), B operand (ax | ay), C operand |b|^2.
+// Vertices are the MFMA's M side and points its N side, so a lane owns ONE point (column n = lane & 31) and receives 16
+// vertices of it per MFMA in its accumulator registers.  Per MFMA the VALU only reduces those 16 values with v_min3 and
+// keeps (best value, id of the 16-vertex group it came from): ~11 instructions per 1024 pairs instead of ~7 per pair in the
+// VALU-only kernel above, which ran at 95 % of the fp32 issue rate.  The winning vertex inside the winning group is
+// recovered once per point at the end (16 candidates, ascending index, strict <), and groups are visited in ascending
+// index with strict <, so equal distances resolve to the lowest index as tf.argmin does.  The two lane halves see
+// different vertex subsets of the same point and are merged once at the end.
+// In exact arithmetic the choice is the reference's; in fp32 it can differ between candidates whose distances agree to
+// rounding (the reference's own expanded form has that noise: entries ~1e5 px^2 carry ~8e-3 px^2 of rounding).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#define NN_PG 8  // point groups of 32 per wave -> 1024 points per 256-thread block
+__global__ __launch_bounds__(256) void nn_a2b_mfma_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
+                                                          const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
+                                                          int nblk) {
+    __shared__ __attribute__((aligned(16))) float sX[NN_BT];  // -2 bx
+    __shared__ __attribute__((aligned(16))) float sY[NN_BT];  // -2 by
+    __shared__ __attribute__((aligned(16))) float sN[NN_BT];  // |b|^2 (+inf for padding vertices: never selected)
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int cnt = counts[b];
+    const int base = blockIdx.x * 256 * NN_PT;
+    if (base >= cnt) {
+        if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = 0.f;
+        return;
+    }
+    const float* Bp = v2d + (size_t)b * P * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    float px[NN_PG], py[NN_PG], best[NN_PG];
+    int bgrp[NN_PG];  // id of the best 16-vertex group: 2 * (global 32-vertex group) + half
+#pragma unroll
+    for (int g = 0; g < NN_PG; ++g) {
+        const int idx = min(base + wave * (32 * NN_PG) + g * 32 + l31, cnt - 1);
+        px[g] = pts[((size_t)b * HW + idx) * 2];
+        py[g] = pts[((size_t)b * HW + idx) * 2 + 1];
+        best[g] = __builtin_inff();
+        bgrp[g] = hi;
+    }
+    for (int p0 = 0; p0 < P; p0 += NN_BT) {
+        const int n = min(NN_BT, P - p0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < NN_BT; i += 256) {
+            float bx = 0.f, by = 0.f, bn = __builtin_inff();
+            if (i < n) {
+                bx = Bp[2 * (p0 + i)];
+                by = Bp[2 * (p0 + i) + 1];
+                bn = bx * bx + by * by;
+            }
+            sX[i] = -2.0f * bx;
+            sY[i] = -2.0f * by;
+            sN[i] = bn;
+        }
+        __syncthreads();
+        const int ngroups = (n + 31) >> 5;
+        for (int vg = 0; vg < ngroups; ++vg) {
+            const float a = hi ? sY[vg * 32 + l31] : sX[vg * 32 + l31];
+            f32x16_t qz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 q = *reinterpret_cast<const float4*>(&sN[vg * 32 + 8 * j + 4 * hi]);
+                qz[4 * j] = q.x;
+                qz[4 * j + 1] = q.y;
+                qz[4 * j + 2] = q.z;
+                qz[4 * j + 3] = q.w;
+            }
+            const int gid = 2 * ((p0 >> 5) + vg) + hi;
+#pragma unroll
+            for (int g = 0; g < NN_PG; ++g) {
+                const f32x16_t d = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hi ? py[g] : px[g], qz, 0, 0, 0);
+                const float m0 = fminf(fminf(d[0], d[1]), d[2]);
+                const float m1 = fminf(fminf(d[3], d[4]), d[5]);
+                const float m2 = fminf(fminf(d[6], d[7]), d[8]);
+                const float m3 = fminf(fminf(d[9], d[10]), d[11]);
+                const float m4 = fminf(fminf(d[12], d[13]), d[14]);
+                const float m5 = fminf(fminf(m0, m1), d[15]);
+                const float m6 = fminf(fminf(m2, m3), m4);
+                const float gm = fminf(m5, m6);
+                const bool lt = gm < best[g];  // strict: the first (lowest-index) group keeps a tie
+                best[g] = lt ? gm : best[g];
+                bgrp[g] = lt ? gid : bgrp[g];
+            }
+        }
+    }
+    float contrib = 0.f;
+#pragma unroll
+    for (int g = 0; g < NN_PG; ++g) {
+        // merge the halves (lower value, then lower group id), then recover the vertex inside the winning 16-vertex group
+        const float ob = __shfl_xor(best[g], 32, 64);
+        const int og = __shfl_xor(bgrp[g], 32, 64);
+        const bool take = (ob < best[g]) || (ob == best[g] && og < bgrp[g]);
+        const int grp = take ? og : bgrp[g];
+        const int idx = base + wave * (32 * NN_PG) + g * 32 + l31;
+        if (hi == 0 && idx < cnt) {
+            const int v0 = (grp >> 1) * 32 + 4 * (grp & 1);
+            float bd = __builtin_inff(), vx = 0.f, vy = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int vi = v0 + (e & 3) + 8 * (e >> 2);  // ascending with e
+                if (vi < P) {
+                    const float bx = Bp[2 * vi], by = Bp[2 * vi + 1];
+                    const float dd = fmaf(-2.0f * bx, px[g], fmaf(-2.0f * by, py[g], bx * bx + by * by));
+                    if (dd < bd) {
+                        bd = dd;
+                        vx = bx;
+                        vy = by;
+                    }
+                }
+            }
+            contrib += fabsf(px[g] - vx) + fabsf(py[g] - vy);
+        }
     }
     const float s = block_sum_256(contrib, red);
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = s;
@@ -335,7 +454,15 @@ hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H
     hipLaunchKernelGGL(sil_compact_kernel, dim3(B), dim3(256), 0, st, seg, HW, W, pts, counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
+    static int a2b_valu = -1;
+    if (a2b_valu < 0) {
+        const char* e = getenv("HPE_MESH_A2B");  // "valu": the VALU-only search (A/B comparisons)
+        a2b_valu = (e && e[0] == 'v') ? 1 : 0;
+    }
+    if (a2b_valu)
+        hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
+    else
+        hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (grid_path) {
