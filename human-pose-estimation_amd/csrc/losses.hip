@@ -45,35 +45,40 @@ __global__ __launch_bounds__(256) void kp_loss_kernel(const float* __restrict__ 
 }
 
 // ordered compaction of the silhouette pixels of image b: pts[b][i] = (x = col, y = row), row-major order
-// (tf.where order; src/trainer.py:291, src/ops.py:123-125).
+// (tf.where order; src/trainer.py:291, src/ops.py:123-125).  Each of the 4 waves owns a contiguous quarter of the image:
+// pass 1 counts (ballot + popcount), the 4 totals give each wave its output offset, pass 2 writes -- coalesced reads, no
+// barrier inside the loops.
 __global__ __launch_bounds__(256) void sil_compact_kernel(const float* __restrict__ seg, int HW, int W, float* __restrict__ pts,
                                                           int* __restrict__ counts) {
-    __shared__ int scan[256];
+    __shared__ int wtot[4];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int chunk = (HW + 255) / 256;
-    const int lo = t * chunk, hi = min(lo + chunk, HW);
+    const int lane = t & 63, wave = t >> 6;
+    const int quarter = (HW + 3) / 4;
+    const int lo = wave * quarter, hi = min(lo + quarter, HW);
     const float* s = seg + (size_t)b * HW;
     int c = 0;
-    for (int i = lo; i < hi; ++i) c += s[i] > 0.f ? 1 : 0;
-    scan[t] = c;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool on = i < hi && s[i] > 0.f;
+        c += __popcll(__ballot(on));
+    }
+    if (lane == 0) wtot[wave] = c;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
-        const int v = (t >= off) ? scan[t - off] : 0;
-        __syncthreads();
-        scan[t] += v;
-        __syncthreads();
-    }
-    int pos = scan[t] - c;
+    int pos = 0;
+    for (int w = 0; w < wave; ++w) pos += wtot[w];
     float* o = pts + (size_t)b * HW * 2;
-    for (int i = lo; i < hi; ++i) {
-        if (s[i] > 0.f) {
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool on = i < hi && s[i] > 0.f;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int k = pos + __popcll(m & ((1ull << lane) - 1ull));
             const int y = i / W;
-            o[2 * pos] = (float)(i - y * W);
-            o[2 * pos + 1] = (float)y;
-            ++pos;
+            *reinterpret_cast<float2*>(&o[2 * k]) = make_float2((float)(i - y * W), (float)y);
         }
+        pos += __popcll(m);
     }
-    if (t == 255) counts[b] = scan[255];
+    if (t == 0) counts[b] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
 }
 
 // direction A -> B: every silhouette point a finds its nearest mesh vertex, contributes |a - b*|_1.
@@ -149,7 +154,9 @@ __global__ __launch_bounds__(256) void nn_a2b_kernel(const float* __restrict__ p
 // rounding (the reference's own expanded form has that noise: entries ~1e5 px^2 carry ~8e-3 px^2 of rounding).
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #define NN_PG 8  // point groups of 32 per wave -> 1024 points per 256-thread block
-__global__ __launch_bounds__(256) void nn_a2b_mfma_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
+// (the explicit waves-per-SIMD bound makes hipcc keep the MFMA results in VGPRs; without it they land in AGPRs and every value
+// costs an extra v_accvgpr_read before the VALU can touch it)
+__global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
                                                           const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
                                                           int nblk) {
     __shared__ __attribute__((aligned(16))) float sX[NN_BT];  // -2 bx
@@ -204,20 +211,27 @@ __global__ __launch_bounds__(256) void nn_a2b_mfma_kernel(const float* __restric
                 qz[4 * j + 3] = q.w;
             }
             const int gid = 2 * ((p0 >> 5) + vg) + hi;
+            // four MFMAs in flight, then their reductions: the VALU work of one batch covers the MFMA latency of the next
 #pragma unroll
-            for (int g = 0; g < NN_PG; ++g) {
-                const f32x16_t d = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hi ? py[g] : px[g], qz, 0, 0, 0);
-                const float m0 = fminf(fminf(d[0], d[1]), d[2]);
-                const float m1 = fminf(fminf(d[3], d[4]), d[5]);
-                const float m2 = fminf(fminf(d[6], d[7]), d[8]);
-                const float m3 = fminf(fminf(d[9], d[10]), d[11]);
-                const float m4 = fminf(fminf(d[12], d[13]), d[14]);
-                const float m5 = fminf(fminf(m0, m1), d[15]);
-                const float m6 = fminf(fminf(m2, m3), m4);
-                const float gm = fminf(m5, m6);
-                const bool lt = gm < best[g];  // strict: the first (lowest-index) group keeps a tie
-                best[g] = lt ? gm : best[g];
-                bgrp[g] = lt ? gid : bgrp[g];
+            for (int g0 = 0; g0 < NN_PG; g0 += 4) {
+                f32x16_t d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hi ? py[g0 + u] : px[g0 + u], qz, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u;
+                    const float m0 = fminf(fminf(d[u][0], d[u][1]), d[u][2]);
+                    const float m1 = fminf(fminf(d[u][3], d[u][4]), d[u][5]);
+                    const float m2 = fminf(fminf(d[u][6], d[u][7]), d[u][8]);
+                    const float m3 = fminf(fminf(d[u][9], d[u][10]), d[u][11]);
+                    const float m4 = fminf(fminf(d[u][12], d[u][13]), d[u][14]);
+                    const float m5 = fminf(fminf(m0, m1), d[u][15]);
+                    const float m6 = fminf(fminf(m2, m3), m4);
+                    const float gm = fminf(m5, m6);
+                    const bool lt = gm < best[g];  // strict: the first (lowest-index) group keeps a tie
+                    best[g] = lt ? gm : best[g];
+                    bgrp[g] = lt ? gid : bgrp[g];
+                }
             }
         }
     }
@@ -409,18 +423,26 @@ __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long lo
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blk_off + blockIdx.x] = s;
 }
 
-// out[0] = sum_b ( sum of image b's partials ) / (3 + P), images added in index order (src/ops.py:129-136)
+// out[0] = sum_b ( sum of image b's partials ) / (3 + P), images added in index order (src/ops.py:129-136).
+// A wave sums one image's partials with shuffles (no barrier); the per-image values are then added sequentially in
+// image order by one thread, so the result does not depend on the launch geometry.
 __global__ __launch_bounds__(256) void mesh_loss_finish_kernel(const float* __restrict__ partial, int B, int nblk, int nused, int P,
                                                                float* __restrict__ out) {
-    __shared__ float red[4];
-    float total = 0.f;
-    for (int b = 0; b < B; ++b) {
+    extern __shared__ float per_image[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 4) {
         float v = 0.f;
-        for (int i = threadIdx.x; i < nused; i += 256) v += partial[(size_t)b * nblk + i];
-        const float s = block_sum_256(v, red);
-        total += s / (float)(3 + P);
+        for (int i = lane; i < nused; i += 64) v += partial[(size_t)b * nblk + i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) per_image[b] = v / (float)(3 + P);
     }
-    if (threadIdx.x == 0) out[0] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int b = 0; b < B; ++b) total += per_image[b];
+        out[0] = total;
+    }
 }
 
 }  // namespace
@@ -478,6 +500,6 @@ hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // zero-fill is not needed: every partial slot in [0, nA + nB) is written; finish sums exactly those
-    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, B, nblk, nA + nB, P, out);
+    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), (size_t)B * sizeof(float), st, partial, B, nblk, nA + nB, P, out);
     return hipGetLastError();
 }
