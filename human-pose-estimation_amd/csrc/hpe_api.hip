@@ -390,7 +390,10 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
 // back-to-back launches on one stream and therefore runs unchunked.
 hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
     int nstream = c->n_streams;
-    if (c->timing >= 2 || nstream < 2 || B < 2 * 32) nstream = 1;
+    // a chunk needs >= 64 images to keep its own launches efficient (measured: B = 64 is 7 % faster unchunked, B = 128 best
+    // with 2 chunks, B = 256 equal for 2-4; profiles/r01/g_wino_chunk_rule.txt)
+    if (nstream > B / 64) nstream = B / 64;
+    if (c->timing >= 2 || nstream < 2) nstream = 1;
     if (nstream == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
     // chunk size: HPE_CHUNK images (default: one chunk per stream); chunks go round-robin over the streams
     int per = (B + nstream - 1) / nstream;

@@ -212,6 +212,31 @@ def test_winograd_encoder_features_match_direct(engines_direct_and_wino, assets)
     assert rel(fw, ref) < TOL and rel(fd, ref) < TOL
 
 
+def test_winograd_chunked_encoder_matches_direct(assets):
+    """B = 130 runs as two batch chunks of 65 on two streams (one chunk per >= 64 images), each with its own slice of the
+    Winograd workspace and the product's default thresholds; the features must equal the all-direct context's."""
+    feats = []
+    img = gpu(synthetic.make_images(130, seed=99))
+    for env in ({"HPE_WINO_MINC": "0"}, {}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            e = hpe_amd.HpeEngine(device=0, max_batch=130)
+            e.load_encoder(assets["enc"])
+            e.finalize()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        feats.append(cpu(e.encoder(img)))
+        e.close()
+    assert rel(feats[1], feats[0]) < 2e-5
+    ref = O.resnet50_features(cpu(img[64:66]), assets["enc"])  # images straddling the chunk boundary
+    assert rel(feats[1][64:66], ref) < TOL
+
+
 def test_winograd_streamk_matches_direct(assets):
     """Opt-in persistent stream-K scheduling (HPE_WINO_STREAMK=1): at B = 90 nearly every workgroup of the res4 launch (69 tile
     blocks on 64 teams) and half of the res3 launch (276 on 128) computes a cut tile block in two parts that meet through the
