@@ -207,11 +207,12 @@ int pick_tile(int M, int N, int K) {
     static int shortk = -2;
     if (shortk == -2) {
         const char* e = getenv("HPE_SHORTK_TILE");
-        shortk = e ? atoi(e) : TILE_128x128_W8;
+        shortk = e ? atoi(e) : TILE_128x64_W8;
     }
-    // K <= 64 (the 64 -> 256 expand / projection layers of stage 2): two k-slabs only, the launch is all epilogue ->
-    // the widest rows per workgroup and 8 waves to issue the row stores win (d_tile_sweep.txt, res2*_branch2c / branch1)
-    if (K <= 64 && M >= 150000) return shortk;
+    // K <= 128 on the huge-M maps (the C -> 4C expand / projection layers of stages 2 and 3): two to four k-slabs only, the
+    // launch is all epilogue and HBM bound -> 8 waves to issue the row stores and residual loads win; 128x64 beats 128x128
+    // (profiles/r01/h_tile_128x64w8.txt: res2*_branch2c 0.41-0.43 -> 0.37-0.38 ms, res3*_branch2c 0.31 -> 0.28 ms)
+    if (K <= 128 && M >= 150000) return shortk;
     if (M >= 150000) return TILE_64x128;
     return TILE_64x64;
 }
