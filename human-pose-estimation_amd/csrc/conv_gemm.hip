@@ -458,7 +458,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
                     v.z = fmaxf(v.z, 0.f);
                     v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n) = v;
+                if (p.y_slab8)
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)(n >> 3) * p.M + m) * 8 + (n & 7)) = v;
+                else
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n) = v;
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -530,7 +533,10 @@ __device__ __forceinline__ void conv_epilogue(const GemmArgs& p, float* lds, f32
                     v.z = fmaxf(v.z, 0.f);
                     v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n) = v;
+                if (p.y_slab8)
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)(n >> 3) * p.M + m) * 8 + (n & 7)) = v;
+                else
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n) = v;
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -835,6 +841,7 @@ hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st) {
     if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return hipErrorInvalidValue;
     // vector epilogue: 16-B aligned rows of y / residual
     if ((p.ldy % 4) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
+    if (p.y_slab8 && (p.N % 8) != 0) return hipErrorInvalidValue;
     if (p.res && ((p.ldres % 4) != 0 || ((uintptr_t)p.res & 15) != 0)) return hipErrorInvalidValue;
     if (((uintptr_t)p.x & 15) != 0 || ((uintptr_t)p.w & 15) != 0) return hipErrorInvalidValue;
     const int bn = (tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x128_W8 || tile == TILE_256x128_W8) ? 128 : 64;

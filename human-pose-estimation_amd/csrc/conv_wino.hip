@@ -378,6 +378,261 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_streamk_kernel(WinoArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused input transform (56x56 and 28x28 maps)
+// For the large maps the blocked V costs more HBM traffic than the layer is worth (C = 64: 1.6 GB per layer), so V never
+// leaves the chip here.  The producing 1x1 convolution writes its output channel-slab major, Xs[slab of 8 ch][pixel][8]
+// (GemmArgs::y_slab8), which makes the 8-channel slab of a row of pixels contiguous.  A workgroup owns R consecutive
+// tile rows of the batch (R * TW <= 64 tiles: 2 x 28 on the 56x56 maps, 4 x 14 on 28x28; the batch is one tall stack of
+// tile rows, so every workgroup is full).  Per slab:
+//   * the 4 input rows of each of its tile rows arrive by LDS-DMA as 16-B chunks in the layout
+//     raw[tile row][input row 4][half 2][pixel parity 2][pixel / 2][4 ch]  (zero page for the halo) -- ~15 KB;
+//   * thread (tile = lane, wave = (half, xi)) reads 2 rows x 4 pixels from it (lanes hit consecutive 16-B slots:
+//     conflict-free), forms row xi of B^T d B for its 4 channels and writes the 4 components into the V slab image the
+//     MFMA loop reads -- exactly the bytes wino_input_kernel would have written to HBM;
+//   * the MFMA work on slab s overlaps the transform of slab s + 1 and the DMAs of U(s + 1) and raw(s + 2).
+// LDS: V 2 x 32 KB + U 2 x 32 KB + raw 2 x 15 KB = 158 KB of the 160 KB.
+struct WinoFusedArgs {
+    const float* Xs;     // [S][M][8], M = B * H * W
+    const float* U;
+    const float* scale;
+    const float* shift;
+    const float* zero;   // >= 16 B of zeros
+    float* y;            // NHWC [M][ldy]
+    int H, W, TW, TH;    // map, tiles per row / per column
+    int R;               // tile rows per workgroup
+    int NG;              // tile rows in the batch (B * TH)
+    int n_blk, n_nt, S;
+    int NC;              // raw chunks per slab = R * 4 * 2 * 2 * (TW + 1)
+    long M;
+    int ldy, relu;
+};
+
+constexpr int RAWF = 960 * 4;  // floats per raw buffer (960 chunks >= 2*4*4*29 = 928 and 4*4*4*15 = 960)
+constexpr int FUSED_LDS_FLOATS = 4 * OPER + 2 * RAWF;
+
+__global__ __launch_bounds__(512, 2) void wino_fused_kernel(WinoFusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* rawb = lds + 4 * OPER;
+
+    const int total = p.n_blk * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int blk = lid / p.n_nt;
+    const int nt = lid - blk * p.n_nt;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hi = lane >> 5;
+    const int TW1 = p.TW + 1;
+
+    // ---- raw DMA sources: chunk slot c = (i * 8 + wave) * 64 + lane, i = 0, 1 -> (tile row, input row, half, parity, idx)
+    long rsrc[2];  // float offset inside a slab of Xs, or -1 for the zero page
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (i * 8 + wave) * 64 + lane;
+        long off = -1;
+        if (c < p.NC) {
+            const int idx = c % TW1;
+            int r = c / TW1;
+            const int par = r & 1;
+            r >>= 1;
+            const int h = r & 1;
+            r >>= 1;
+            const int a = r & 3;
+            const int trl = r >> 2;
+            const int g = blk * p.R + trl;
+            if (g < p.NG) {
+                const int b = g / p.TH;
+                const int ty = g - b * p.TH;
+                const int iy = 2 * ty - 1 + a;
+                const int px = 2 * idx + par - 1;
+                if (iy >= 0 && iy < p.H && px >= 0 && px < p.W) off = ((long)(b * p.H + iy) * p.W + px) * 8 + h * 4;
+            }
+        }
+        rsrc[i] = off;
+    }
+    const int n_raw_instr = (p.NC + 63) >> 6;  // wave-instructions per slab (<= 15)
+    const float* usrc = p.U + (size_t)nt * p.S * OPER + wave * 1024 + lane * 4;
+
+    auto issue_raw = [&](int s, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i * 8 + wave < n_raw_instr) {
+                const float* src = rsrc[i] >= 0 ? p.Xs + (size_t)s * p.M * 8 + rsrc[i] : p.zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(rawb + buf * RAWF + (i * 8 + wave) * 256), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_u = [&](int s, int buf) {
+        float* dstu = lds + buf * (2 * OPER) + OPER + wave * 1024;
+        const float* su = usrc + (size_t)s * OPER;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(su + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dstu + i * 256), 16, 0, 0);
+    };
+
+    // ---- transform role: tile = lane, wave = (half, xi)
+    const int th = wave & 1, xi = wave >> 1;
+    const int n_tiles = p.R * p.TW;
+    const bool t_live = lane < n_tiles;
+    const int t_trl = t_live ? lane / p.TW : 0;
+    const int t_tx = t_live ? lane - t_trl * p.TW : 0;
+    // row xi of B^T d uses input rows (ra, rb): xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int ra = (xi == 0) ? 0 : (xi == 2 ? 2 : 1);
+    const int rb = (xi == 0) ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sgn = (xi == 1) ? 1.f : -1.f;
+    // raw chunk (floats) of input row a, pixel 2 tx - 1 + e: parity e & 1, idx tx + (e >> 1)
+    const int raw_a = (((t_trl * 4 + ra) * 2 + th) * 2) * TW1 + t_tx;
+    const int raw_b = (((t_trl * 4 + rb) * 2 + th) * 2) * TW1 + t_tx;
+    auto transform = [&](int rbuf, int vbuf) {
+        if (!t_live) return;
+        const float* rw = rawb + rbuf * RAWF;
+        f32x4 r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = ((e & 1) * TW1 + (e >> 1)) * 4;
+            const f32x4 da = *reinterpret_cast<const f32x4*>(rw + raw_a * 4 + o);
+            const f32x4 db = *reinterpret_cast<const f32x4*>(rw + raw_b * 4 + o);
+            r[e] = da + sgn * db;
+        }
+        float* v = lds + vbuf * (2 * OPER) + (((xi * 4) * 2 + th) * 64 + lane) * 4;
+        *reinterpret_cast<f32x4*>(v + 0 * 512) = r[0] - r[2];
+        *reinterpret_cast<f32x4*>(v + 1 * 512) = r[1] + r[2];
+        *reinterpret_cast<f32x4*>(v + 2 * 512) = r[2] - r[1];
+        *reinterpret_cast<f32x4*>(v + 3 * 512) = r[1] - r[3];
+    };
+
+    f32x16 acc[2][2][2];
+    zero_acc(acc);
+    const int frag = ((2 * wave) * 2 + hi) * 256 + (lane & 31) * 4;
+    const int S = p.S;
+
+    issue_raw(0, 0);
+    if (S > 1) issue_raw(1, 1);
+    issue_u(0, 0);
+    // rows of V that belong to no tile (n_tiles < 64) are never written by the transform: clear them once in both buffers so
+    // that the MFMAs do not chew on stale LDS contents (their outputs are masked anyway)
+    if (n_tiles < 64) {
+        const int dead = 64 - n_tiles;  // rows n_tiles .. 63 of each of the 32 (component, half) planes, 2 buffers
+        for (int i = t; i < 2 * 32 * dead; i += 512) {
+            const int row = n_tiles + i % dead;
+            const int plane = (i / dead) & 31;
+            const int buf = i / (dead * 32);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(lds + buf * (2 * OPER) + (plane * 64 + row) * 4) = z;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);  // vmcnt(4): everything but the 4 newest DMAs (U(0), issued last) has landed: raw(0), raw(1)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    transform(0, 0);
+    __syncthreads();  // V(0) written by every wave; raw(1), U(0) landed
+    for (int s = 0; s < S; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < S) issue_u(s + 1, nxt);
+        if (s + 2 < S) issue_raw(s + 2, cur);
+        const int cb = cur * (2 * OPER);
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[c][i] = *reinterpret_cast<const f32x4*>(&lds[cb + frag + c * 512 + i * 128]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[c][j] = *reinterpret_cast<const f32x4*>(&lds[cb + OPER + frag + c * 512 + j * 128]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][i][ks], fb[0][j][ks], acc[0][i][j], 0, 0, 0);
+        if (s + 1 < S) transform(nxt, nxt);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][i][ks], fb[1][j][ks], acc[1][i][j], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---- epilogue (as wino_epilogue, with this kernel's tile -> pixel mapping)
+    const int n0 = nt * WN_;
+    const int em = t >> 4;
+    const int eq = (t & 15) * 4;
+    const int n = n0 + eq;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    lds[((2 * wave + c) * 32 + m) * 64 + 32 * j + (lane & 31)] = acc[c][i][j][e];
+                }
+        __syncthreads();
+        const int lt = 32 * i + em;
+        const int trl = lt / p.TW;
+        const int tx = lt - trl * p.TW;
+        const int g = blk * p.R + trl;
+        if (lt < n_tiles && g < p.NG) {
+            f32x4 Mv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Mv[c] = *reinterpret_cast<const f32x4*>(&lds[(c * 32 + em) * 64 + eq]);
+            f32x4 u0[4], u1[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                u0[v] = Mv[v] + Mv[4 + v] + Mv[8 + v];
+                u1[v] = Mv[4 + v] - Mv[8 + v] - Mv[12 + v];
+            }
+            f32x4 o[2][2];
+            o[0][0] = u0[0] + u0[1] + u0[2];
+            o[0][1] = u0[1] - u0[2] - u0[3];
+            o[1][0] = u1[0] + u1[1] + u1[2];
+            o[1][1] = u1[1] - u1[2] - u1[3];
+            const int b = g / p.TH;
+            const int ty = g - b * p.TH;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int oy = 2 * ty + dy, ox = 2 * tx + dx;
+                    f32x4 v = o[dy][dx] * sc + sh;
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                }
+        }
+    }
+}
+
+// NHWC -> channel-slab major (only the debug entry point needs it: in the network the producing convolution writes Xs itself)
+__global__ __launch_bounds__(256) void nhwc_to_slab8_kernel(const float* __restrict__ x, float* __restrict__ xs, long M, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one float4
+    const long total = M * C / 4;
+    if (i >= total) return;
+    const long m = i / (C / 4);
+    const int c = (int)(i - m * (C / 4)) * 4;
+    *reinterpret_cast<f32x4*>(xs + ((size_t)(c >> 3) * M + m) * 8 + (c & 7)) = *reinterpret_cast<const f32x4*>(x + m * C + c);
+}
+
 }  // namespace
 
 size_t hpe_wino_v_floats(int B, int H, int W, int C) {
@@ -434,5 +689,61 @@ hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const 
     } else {
         hipLaunchKernelGGL(wino_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(512), LDS_BYTES, st, p);
     }
+    return hipGetLastError();
+}
+
+// fused variant for even maps with W / 2 <= 64 tiles per row: xs is channel-slab major [C/8][B*H*W][8]
+hipError_t hpe_launch_wino_fused_conv3(const float* xs, const float* U, const float* scale, const float* shift, const float* zero16, float* y,
+                                       int ldy, int B, int H, int W, int C, int N, int relu, hipStream_t st) {
+    if (C % 8 != 0 || N % 64 != 0 || ldy % 4 != 0 || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || !zero16) return hipErrorInvalidValue;
+    const int TW = W / 2, TH = H / 2;
+    if (TW > 64) return hipErrorInvalidValue;
+    int R = 64 / TW;
+    if (R > TH * B) R = TH * B;
+    const int NC = R * 4 * 2 * 2 * (TW + 1);
+    if (NC > 960) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    constexpr int LDS_BYTES = FUSED_LDS_FLOATS * (int)sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    WinoFusedArgs p{};
+    p.Xs = xs;
+    p.U = U;
+    p.scale = scale;
+    p.shift = shift;
+    p.zero = zero16;
+    p.y = y;
+    p.H = H;
+    p.W = W;
+    p.TW = TW;
+    p.TH = TH;
+    p.R = R;
+    p.NG = B * TH;
+    p.n_blk = (p.NG + R - 1) / R;
+    p.n_nt = N / 64;
+    p.S = C / 8;
+    p.NC = NC;
+    p.M = (long)B * H * W;
+    p.ldy = ldy;
+    p.relu = relu;
+    hipLaunchKernelGGL(wino_fused_kernel, dim3(p.n_blk * p.n_nt), dim3(512), LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+int hpe_wino_fused_items(int B, int H, int W, int N) {
+    const int TW = W / 2, TH = H / 2;
+    if ((H & 1) || (W & 1) || TW > 64 || TW < 1) return 0;
+    int R = 64 / TW;
+    if (R * 4 * 2 * 2 * (TW + 1) > 960) return 0;
+    return ((B * TH + R - 1) / R) * (N / 64);
+}
+
+hipError_t hpe_launch_nhwc_to_slab8(const float* x, float* xs, long M, int C, hipStream_t st) {
+    if (C % 8 != 0 || M < 1) return hipErrorInvalidValue;
+    const long total = M * C / 4;
+    hipLaunchKernelGGL(nhwc_to_slab8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, xs, M, C);
     return hipGetLastError();
 }

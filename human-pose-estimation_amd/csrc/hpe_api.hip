@@ -151,6 +151,7 @@ struct hpe_ctx {
     int n_cu = 0;
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     int wino_min_items = 128; // ... when the launch has at least this many workgroups
+    int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
     // timing
@@ -236,13 +237,25 @@ int pick_tile_bf16(int M, int N) {
     } while (0)
 
 // one conv layer (+BN fold, +residual, +ReLU) through the implicit-GEMM kernel
+enum { CONV_OUT_SLAB8 = 1, CONV_IN_SLAB8 = 2 };
+
+// the 3x3 layer idx runs as the fused Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
+bool use_wino_fused(const hpe_ctx* c, int idx, int B) {
+    const ConvSpec& s = specs()[idx];
+    return c->wino_fused && !c->bf16 && c->conv[idx].wino_u && s.kh == 3 && s.stride == 1 && s.hin >= 28 &&
+           hpe_wino_fused_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
+}
+
 hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
-                    float* wino_v = nullptr, int slot = 0) {
+                    float* wino_v = nullptr, int slot = 0, int flags = 0) {
     const ConvSpec& s = specs()[idx];
     const ConvLayer& L = c->conv[idx];
+    if (flags & CONV_IN_SLAB8)
+        return hpe_launch_wino_fused_conv3(x, L.wino_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
     // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
     // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
-    if (L.wino_u && wino_v && !res && (long)((B * ((s.hin + 1) / 2) * ((s.hin + 1) / 2) + 63) / 64) * (s.cout / 64) >= c->wino_min_items)
+    if (L.wino_u && wino_v && !res && s.cin >= c->wino_min_c &&
+        (long)((B * ((s.hin + 1) / 2) * ((s.hin + 1) / 2) + 63) / 64) * (s.cout / 64) >= c->wino_min_items)
     {
         WinoStreamK sk{};
         if (c->wino_ws && slot >= 0 && slot < 4) {
@@ -277,6 +290,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     p.cin_slabs = s.cin / 32;
     p.lda = s.cin;
     p.zero = c->zeros;
+    p.y_slab8 = (flags & CONV_OUT_SLAB8) ? 1 : 0;
     if (B < 64) {  // chunk streams are off below 64 images, so one workspace is enough
         p.partial = c->partial;
         p.partial_floats = c->partial_floats;
@@ -326,10 +340,10 @@ hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const fl
 }
 
 hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
-                      float* wino_v = nullptr, int slot = 0) {
+                      float* wino_v = nullptr, int slot = 0, int flags = 0) {
     const bool t2 = c->timing >= 2;
     if (t2) HIPE(hipEventRecord(c->cev0[idx], st));
-    HIPE(run_conv(c, idx, x, B, res, relu, y, st, wino_v, slot));
+    HIPE(run_conv(c, idx, x, B, res, relu, y, st, wino_v, slot, flags));
     if (t2) HIPE(hipEventRecord(c->cev1[idx], st));
     return hipSuccess;
 }
@@ -366,8 +380,9 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
         for (int b = 0; b < nblk[stg]; ++b) {
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
-            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st));
-            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot));
+            const bool fz = use_wino_fused(c, i2b, B);  // then T1 is channel-slab major and never leaves this pair of launches
+            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, fz ? CONV_OUT_SLAB8 : 0));
+            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot, fz ? CONV_IN_SLAB8 : 0));
             const float* res = cur;
             if (first) {
                 // projection shortcut (conv_block), no ReLU before the add
@@ -584,6 +599,8 @@ int hpe_finalize(hpe_ctx* c) {
         c->wino_min_c = e ? atoi(e) : 128;
         e = getenv("HPE_WINO_MIN_ITEMS");
         c->wino_min_items = e ? atoi(e) : 128;
+        e = getenv("HPE_WINO_FUSED");
+        c->wino_fused = (e ? atoi(e) : 1) && c->wino_min_c > 0;
     }
     // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
     for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {
@@ -617,7 +634,8 @@ int hpe_finalize(hpe_ctx* c) {
                     for (int n = 0; n < s.cout; ++n) wt[(size_t)n * L.k_pad + k] = src[n];
                 }
         if ((rc = upload(c, &L.w, wt))) return rc;
-        if (c->wino_min_c > 0 && s.kh == 3 && s.stride == 1 && s.cin >= c->wino_min_c && s.cin % 32 == 0 && s.cout % 64 == 0) {
+        if (c->wino_min_c > 0 && s.kh == 3 && s.stride == 1 && s.cin % 32 == 0 && s.cout % 64 == 0 &&
+            (s.cin >= c->wino_min_c || (c->wino_fused && s.hin >= 28))) {
             // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in double; layout [cout/64][cin/8][16][2][64][4]
             static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             const int S = s.cin / 8;
@@ -649,6 +667,9 @@ int hpe_finalize(hpe_ctx* c) {
         if ((rc = upload(c, &L.shift, sh))) return rc;
         std::vector<float>().swap(L.kernel);
     }
+    // constants every part uses: the zero page is the LDS-DMA source of out-of-image taps / halo pixels
+    if ((rc = upload(c, &c->ones, std::vector<float>(1024, 1.f)))) return rc;
+    if ((rc = upload(c, &c->zeros, std::vector<float>(1024, 0.f)))) return rc;
     // ---- regressor: Dense kernels [in,out] -> [out_pad][in_pad]; W1 split into features / theta parts
     if (c->have_regressor) {
         const std::vector<float>& k1 = c->dense[0].kernel;  // [2133][1024]
@@ -674,8 +695,6 @@ int hpe_finalize(hpe_ctx* c) {
         std::vector<float> b3(128, 0.f);
         for (int n = 0; n < HPE_THETA_DIM; ++n) b3[n] = c->dense[2].bias[n];
         if ((rc = upload(c, &c->b3, b3))) return rc;
-        if ((rc = upload(c, &c->ones, std::vector<float>(1024, 1.f)))) return rc;
-        if ((rc = upload(c, &c->zeros, std::vector<float>(1024, 0.f)))) return rc;
         if ((rc = upload(c, &c->mean_dev, std::vector<float>(c->h_mean, c->h_mean + HPE_THETA_DIM)))) return rc;
     }
     // ---- SMPL constants in kernel layouts
@@ -964,6 +983,13 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
     if (idx == 0) {
         HIP_TRY(hpe_launch_pad_input(x, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
         in = c->padded;
+    }
+    if (!residual && use_wino_fused(c, idx, B)) {
+        // the fused Winograd kernel reads channel-slab major input; in the network its 1x1 producer writes that directly
+        const ConvSpec& s = specs()[idx];
+        HIP_TRY(hpe_launch_nhwc_to_slab8(in, c->T1, (long)B * s.hin * s.hin, s.cin, st));
+        HIP_TRY(run_conv(c, idx, c->T1, B, nullptr, relu, y, st, nullptr, 0, CONV_IN_SLAB8));
+        return HPE_OK;
     }
     HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st, c->wino_v));
     return HPE_OK;

@@ -24,6 +24,7 @@ struct GemmArgs {
     size_t partial_floats;
     const float* zero;       // >= 16 B of zeros in global memory (source of out-of-image taps for the LDS-DMA path)
     unsigned long long* dbg;  // diagnostics only (HPE_ABLATION builds): per-workgroup {shader clocks, 100 MHz ticks}
+    int y_slab8;  // 1: y is written channel-slab major, y[(n / 8) * M + m][n % 8] (the layout the fused Winograd kernel reads); needs N % 8 == 0
 };
 
 hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st);
@@ -42,6 +43,12 @@ struct WinoStreamK {
 };
 hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy,
                                  int B, int H, int W, int C, int N, int relu, float* V, const WinoStreamK* sk, hipStream_t st);
+
+// fused-transform variant (56x56 / 28x28 maps): xs is channel-slab major [C/8][B*H*W][8] (GemmArgs::y_slab8 of the producer)
+hipError_t hpe_launch_wino_fused_conv3(const float* xs, const float* U, const float* scale, const float* shift, const float* zero16, float* y,
+                                       int ldy, int B, int H, int W, int C, int N, int relu, hipStream_t st);
+int hpe_wino_fused_items(int B, int H, int W, int N);  // work items of that launch, 0 if the geometry is not supported
+hipError_t hpe_launch_nhwc_to_slab8(const float* x, float* xs, long M, int C, hipStream_t st);
 
 // conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st);
