@@ -699,9 +699,10 @@ hipError_t hpe_launch_wino_fused_conv3(const float* xs, const float* U, const fl
     const int TW = W / 2, TH = H / 2;
     if (TW > 64) return hipErrorInvalidValue;
     int R = 64 / TW;
+    if (R > 960 / (16 * (TW + 1))) R = 960 / (16 * (TW + 1));  // raw buffer: 960 chunks
     if (R > TH * B) R = TH * B;
     const int NC = R * 4 * 2 * 2 * (TW + 1);
-    if (NC > 960) return hipErrorInvalidValue;
+    if (R < 1 || NC > 960) return hipErrorInvalidValue;
     static bool attr_set = false;
     constexpr int LDS_BYTES = FUSED_LDS_FLOATS * (int)sizeof(float);
     if (!attr_set) {
@@ -737,7 +738,8 @@ int hpe_wino_fused_items(int B, int H, int W, int N) {
     const int TW = W / 2, TH = H / 2;
     if ((H & 1) || (W & 1) || TW > 64 || TW < 1) return 0;
     int R = 64 / TW;
-    if (R * 4 * 2 * 2 * (TW + 1) > 960) return 0;
+    if (R > 960 / (16 * (TW + 1))) R = 960 / (16 * (TW + 1));
+    if (R < 1) return 0;
     return ((B * TH + R - 1) / R) * (N / 64);
 }
 

@@ -151,6 +151,7 @@ struct hpe_ctx {
     int n_cu = 0;
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     int wino_min_items = 128; // ... when the launch has at least this many workgroups
+    int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
@@ -242,7 +243,7 @@ enum { CONV_OUT_SLAB8 = 1, CONV_IN_SLAB8 = 2 };
 // the 3x3 layer idx runs as the fused Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
 bool use_wino_fused(const hpe_ctx* c, int idx, int B) {
     const ConvSpec& s = specs()[idx];
-    return c->wino_fused && !c->bf16 && c->conv[idx].wino_u && s.kh == 3 && s.stride == 1 && s.hin >= 28 &&
+    return c->wino_fused && !c->bf16 && c->conv[idx].wino_u && s.kh == 3 && s.stride == 1 && s.hin >= c->wino_fused_min_hw &&
            hpe_wino_fused_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
 }
 
@@ -601,6 +602,8 @@ int hpe_finalize(hpe_ctx* c) {
         c->wino_min_items = e ? atoi(e) : 128;
         e = getenv("HPE_WINO_FUSED");
         c->wino_fused = (e ? atoi(e) : 1) && c->wino_min_c > 0;
+        e = getenv("HPE_WINO_FUSED_MINHW");
+        c->wino_fused_min_hw = e ? atoi(e) : 28;
     }
     // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
     for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {
@@ -635,7 +638,7 @@ int hpe_finalize(hpe_ctx* c) {
                 }
         if ((rc = upload(c, &L.w, wt))) return rc;
         if (c->wino_min_c > 0 && s.kh == 3 && s.stride == 1 && s.cin % 32 == 0 && s.cout % 64 == 0 &&
-            (s.cin >= c->wino_min_c || (c->wino_fused && s.hin >= 28))) {
+            (s.cin >= c->wino_min_c || (c->wino_fused && s.hin >= c->wino_fused_min_hw))) {
             // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in double; layout [cout/64][cin/8][16][2][64][4]
             static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             const int S = s.cin / 8;
