@@ -12,7 +12,7 @@ for N > 1 one RCCL all-gather of the final theta [256,85] per rank over xGMI.  I
 (independent units, no data-path collective besides that gather): weak scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family, the 53 convolution layers (implicit-GEMM
-conv_gemm_f32_dma_kernel; the 3x3 layers with C >= 128 run as fp32 Winograd F(2x2,3x3), which does 2.25x fewer multiplies for
+conv_gemm_f32_dma_kernel; the 3x3 layers run as fp32 Winograd F(2x2,3x3), which does 2.25x fewer multiplies for
 the same layer -- the algorithmic FLOPs priced here are the direct convolution's): achieved = 7.7119 GFLOP/img * 256 img / (encoder span of the last
 timed step, HIP events recorded on the launch stream; the batch-chunk streams overlap their conv launches, so the
 span -- not a sum of overlapping durations -- is the family's time), peak = 157.3 TFLOP/s fp32 MFMA.
@@ -183,8 +183,8 @@ def main():
         PEAK = PEAK_FP32_MFMA_TFLOPS if args.encoder_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roofline = {
             "bound": "mfma",
-            "kernel": ("conv_gemm_f32_dma_kernel (40 layers) + wino_input_kernel/wino_gemm_kernel (the 13 3x3 layers with C >= 128 as "
-                       "fp32 Winograd F(2x2,3x3))" if args.encoder_dtype == "fp32" else "conv_gemm_bf16_dma_kernel")
+            "kernel": ("conv_gemm_f32_dma_kernel (37 layers) + wino_fused_kernel / wino_input_kernel + wino_gemm_kernel (the 16 3x3 layers "
+                       "as fp32 Winograd F(2x2,3x3))" if args.encoder_dtype == "fp32" else "conv_gemm_bf16_dma_kernel")
                       + " -- the 53 conv layers of one step, priced at their direct-convolution FLOPs; batch chunks on %s concurrent streams" % os.environ.get("HPE_STREAMS", "3"),
             "achieved": round(achieved, 3),
             "peak": PEAK,

@@ -6,7 +6,8 @@
 // 16 multiplies per tile and channel pair instead of 36: the MFMA work of these 16 layers (48 % of the encoder's
 // FLOPs) shrinks 2.25x (1.72x on the 7x7 maps, whose 4x4 tile grid covers 8x8).  Arithmetic stays fp32 end to end.
 //
-// Two kernels per layer:
+// Two variants:
+//  (a) 14x14 and 7x7 maps -- two kernels per layer:
 //   wino_input_kernel   x [B,H,W,C] NHWC -> V, HBM bound (reads x once, writes 4x its size).  V is stored in the exact
 //                       byte image the GEMM kernel's LDS staging wants, so that each k-slab of a workgroup is one
 //                       contiguous 32 KB block:   V[tile block of 64][slab of 8 ch][comp 16][half 2][tile 64][4 ch]
@@ -16,11 +17,14 @@
 //                       the barrier in the middle of a slab's MFMA work), then the output
 //                       transform A^T M A through LDS, BN scale/shift, ReLU and 16 B/lane NHWC stores.
 //                       U = G g G^T is precomputed on the host in the same blocked layout.
+//  (b) 56x56 and 28x28 maps -- wino_fused_kernel: the same GEMM with the input transform done inside, from activations the
+//      producing 1x1 convolution wrote channel-slab major (see the comment at the kernel); no V in memory.
 //
-// Why the input transform is not fused into the GEMM: a slab can only hold 8 channels of 64 tiles x 16 components
-// (LDS), i.e. 32 B of every 128 B activation line per pass, and the 1024 lines a workgroup touches per slab do not
-// survive in the 32 KB L1 until the next slab -> 4x L2 traffic.  The blocked V removes the problem at the price of one
-// extra HBM round trip that runs concurrently with another batch chunk's MFMA-bound GEMM (chunk streams).
+// Why (a) does not read NHWC activations directly: a slab can only hold 8 channels of 64 tiles x 16 components (LDS), i.e.
+// 32 B of every 128 B activation line per pass, and the 1024 lines a workgroup touches per slab do not survive in the
+// 32 KB L1 until the next slab -> 4x L2 traffic.  The blocked V removes the problem at the price of one extra HBM round
+// trip that runs concurrently with another batch chunk's MFMA-bound GEMM (chunk streams); the slab-major producer of (b)
+// removes it without that round trip, where whole tile rows of the batch fill a workgroup.
 #include "hpe_internal.h"
 
 namespace {
