@@ -246,10 +246,23 @@ def main():
         last_outs = plans[(step_no[0] - 1) & 1][1]
         j = last_outs[-1]["joints"][:n].cpu().numpy()
         v = last_outs[-1]["verts"][:n].cpu().numpy()
+        def _rel(a, b):
+            return float(np.abs(a - b).max() / np.abs(b).max())
+
         parity = {
+            # "MPJPE vs ref" of BASELINE.json: mean Euclidean distance to the oracle's joints, same inputs and weights, on the
+            # images of the CPU sample taken out of the full-size batch (so the Winograd / chunked paths are what is checked)
             "mpjpe_vs_oracle": float(np.linalg.norm(j - ref["generated_joints"], axis=-1).mean()),
-            "verts_rel_err": float(np.abs(v - ref["generated_verts"]).max() / np.abs(ref["generated_verts"]).max()),
+            "verts_rel_err": _rel(v, ref["generated_verts"]),
+            "bar": "1e-4 relative fp32",
         }
+        if "J_transformed" in last_outs[-1]:
+            j24 = last_outs[-1]["J_transformed"][:n].cpu().numpy()
+            parity["mpjpe24_vs_oracle"] = float(np.linalg.norm(j24 - ref["J_transformed"], axis=-1).mean())
+        if "theta" in last_outs[-1]:
+            parity["theta_rel_err"] = _rel(last_outs[-1]["theta"][:n].cpu().numpy(), ref["theta"])
+        if "kp2d" in last_outs[-1]:
+            parity["kp2d_rel_err"] = _rel(last_outs[-1]["kp2d"][:n].cpu().numpy(), ref["generated_kp2d"])
 
     if rank == 0:
         value = world * B * args.steps / dt
