@@ -9,7 +9,11 @@ import os as _os
 
 # Batch-chunk streams + RCCL's own streams must not share hardware queues (DESIGN.md "Multi-GPU"); only effective when the
 # package is imported before the first HIP call of the process, which is the normal order.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+try:
+    if int(_os.environ.get("GPU_MAX_HW_QUEUES", "0")) < 8:
+        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+except ValueError:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 from . import resnet_spec, synthetic  # noqa: F401,E402
 from ._lib import HpeError  # noqa: F401
