@@ -76,6 +76,9 @@ _PROTOS = {
     "hpe_get_original": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpe_kp_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_mesh_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hpe_val_losses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "hpe_device_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpe_debug_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_debug_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_debug_set_dbg": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -84,6 +87,7 @@ _PROTOS = {
     "hpe_debug_joint_regress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "hpe_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "hpe_get_loss_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "hpe_get_conv_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }
 

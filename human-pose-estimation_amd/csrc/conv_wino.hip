@@ -36,6 +36,7 @@ constexpr int WT = 64;             // tiles per workgroup
 constexpr int WN_ = 64;            // output channels per workgroup
 constexpr int WK = 8;              // channels per slab
 constexpr int OPER = 16 * 2 * 64 * 4;  // floats of one operand (V or U) per slab = 8192 (32 KB)
+constexpr int WINO_LDS_BYTES = 2 * 2 * OPER * (int)sizeof(float);  // wino_gemm_kernel: 2 x (V slab + U slab) = 128 KB
 
 // ------------------------------------------------------------------------------------------------ input transform
 // one thread = (tile, 4 channels); a wave = 8 tiles x 32 channels (full 128-B lines on the read side, 128-B
@@ -111,6 +112,7 @@ struct WinoArgs {
     float* ws;            // [workgroups][128 accumulator floats x 512 threads]
     unsigned* flags;      // [workgroups], holds the epoch of the launch that parked data
     unsigned epoch;
+    unsigned* err;        // device error word of the ctx: bit 0 = a stream-K wait timed out (hpe_device_status reports it)
 };
 
 // main loop over k-slabs [k0, k1) of work item (tb, nt); accumulators are added to (caller zeroes them)
@@ -353,12 +355,18 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_streamk_kernel(WinoArgs p) {
         wino_mainloop(p, lds, tb_whole_end, nt, 0, k_last, acc, wave, lane);
         const int partner = lid + p.n_nt;
         if (t == 0) {
-            // bounded (~1 s): every workgroup reaches its publish before anything it waits for, so the bound is never hit;
-            // it only keeps a logic error from hanging the device (the results would then fail parity)
+            // bounded (~1 s): every workgroup reaches its publish before anything it waits for, so the bound is only hit when
+            // the partner is not resident (CUs held by other streams / a CU mask) or on a logic error.  It keeps the device from
+            // hanging; the output of this tile is then WRONG, which is recorded in the ctx's error word (hpe_device_status).
+            bool ok = false;
             for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (__hip_atomic_load(p.flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch) break;
+                if (__hip_atomic_load(p.flags + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch) {
+                    ok = true;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(8);
             }
+            if (!ok && p.err) atomicOr(p.err, 1u);
         }
         __syncthreads();
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p.ws) + (size_t)partner * (64 * 512) + t;
@@ -639,6 +647,16 @@ __global__ __launch_bounds__(256) void nhwc_to_slab8_kernel(const float* __restr
 
 }  // namespace
 
+// hipFuncSetAttribute applies to the CURRENT device: hpe_finalize calls this once per ctx under its device guard
+hipError_t hpe_wino_init_device() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_streamk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               FUSED_LDS_FLOATS * (int)sizeof(float));
+}
+
 size_t hpe_wino_v_floats(int B, int H, int W, int C) {
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const size_t T = (size_t)B * TH * TW;
@@ -648,15 +666,7 @@ size_t hpe_wino_v_floats(int B, int H, int W, int C) {
 hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy,
                                  int B, int H, int W, int C, int N, int relu, float* V, const WinoStreamK* sk, hipStream_t st) {
     if (C % 32 != 0 || N % 64 != 0 || lda % 4 != 0 || ldy % 4 != 0 || B < 1 || H < 1 || W < 1) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    constexpr int LDS_BYTES = 2 * 2 * OPER * (int)sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_streamk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    constexpr int LDS_BYTES = WINO_LDS_BYTES;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2, TT = TH * TW;
     const long Tl = (long)B * TT;
     if (Tl > (1L << 30)) return hipErrorInvalidValue;
@@ -689,6 +699,7 @@ hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const 
         p.ws = sk->ws;
         p.flags = sk->flags;
         p.epoch = sk->epoch;
+        p.err = sk->err;
         hipLaunchKernelGGL(wino_gemm_streamk_kernel, dim3(sk->n_wg), dim3(512), LDS_BYTES, st, p);
     } else {
         hipLaunchKernelGGL(wino_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(512), LDS_BYTES, st, p);
@@ -707,13 +718,7 @@ hipError_t hpe_launch_wino_fused_conv3(const float* xs, const float* U, const fl
     if (R > TH * B) R = TH * B;
     const int NC = R * 4 * 2 * 2 * (TW + 1);
     if (R < 1 || NC > 960) return hipErrorInvalidValue;
-    static bool attr_set = false;
     constexpr int LDS_BYTES = FUSED_LDS_FLOATS * (int)sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     WinoFusedArgs p{};
     p.Xs = xs;
     p.U = U;

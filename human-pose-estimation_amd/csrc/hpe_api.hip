@@ -112,9 +112,16 @@ constexpr size_t WINO_V_SLACK = 524288;
 
 }  // namespace
 
+// tile-selection overrides (HPE_TILE_WIDE / HPE_TILE_NARROW / HPE_SHORTK_TILE / HPE_TILE_BF16), read once in hpe_finalize
+struct TileKnobs {
+    int force_wide = -1, force_narrow = -1, shortk = TILE_128x64_W8, force_bf16 = -1;
+};
+
 struct hpe_ctx {
     HpeConfig cfg{};
     bool finalized = false;
+    bool dead = false;  // hpe_finalize failed part-way: everything it had allocated was released, the ctx can only be destroyed
+    TileKnobs knobs;
     bool bf16 = false;  // encoder_dtype == 1
     bool have_encoder = false, have_regressor = false, have_smpl = false;
     ConvLayer conv[HPE_NUM_CONV];
@@ -147,6 +154,7 @@ struct hpe_ctx {
     float* wino_v = nullptr;  // Winograd input-transform workspace (nullptr: direct convolution everywhere)
     float* wino_ws = nullptr;       // stream-K parking space, one slot of n_cu workgroups per chunk stream (nullptr: plain grid)
     unsigned* wino_flags = nullptr;
+    unsigned* dev_err = nullptr;  // device error word (bit 0: a stream-K wait timed out -> wrong output), see hpe_device_status
     unsigned wino_epoch = 0;
     int n_cu = 0;
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
@@ -159,6 +167,8 @@ struct hpe_ctx {
     int timing = 0;
     hipEvent_t ev[8]{};
     hipEvent_t cev0[HPE_NUM_CONV]{}, cev1[HPE_NUM_CONV]{};
+    hipEvent_t lev0[16]{}, lev1[16]{}, lev_all[2]{};  // hpe_val_losses: around each stage's pixel -> vertex search / the whole call
+    int loss_timed_stages = 0;
     bool ev_ok = false, timed_valid = false, conv_timed_valid = false;
 };
 
@@ -191,42 +201,25 @@ int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
     return HPE_OK;
 }
 
-int pick_tile(int M, int N, int K) {
+int pick_tile(const TileKnobs& kn, int M, int N, int K) {
     // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
-    static int force_wide = -2, force_narrow = -2;
-    if (force_wide == -2) {
-        const char* e = getenv("HPE_TILE_WIDE");
-        force_wide = e ? atoi(e) : -1;
-        e = getenv("HPE_TILE_NARROW");
-        force_narrow = e ? atoi(e) : -1;
-    }
     const bool wide = N > 64;
-    if (wide && force_wide >= 0) return force_wide;
-    if (!wide && force_narrow >= 0) return force_narrow;
+    if (wide && kn.force_wide >= 0) return kn.force_wide;
+    if (!wide && kn.force_narrow >= 0) return kn.force_narrow;
     // Measured on MI355X (profiles/r01/d_tile_sweep.txt): with LDS-DMA staging the small tiles with 3-5 workgroups
     // per CU beat 128x128 at 2 per CU except on the huge-M layers of stages 2-3.
     if (!wide) return TILE_128x64;
-    static int shortk = -2;
-    if (shortk == -2) {
-        const char* e = getenv("HPE_SHORTK_TILE");
-        shortk = e ? atoi(e) : TILE_128x64_W8;
-    }
     // K <= 128 on the huge-M maps (the C -> 4C expand / projection layers of stages 2 and 3): two to four k-slabs only, the
     // launch is all epilogue and HBM bound -> 8 waves to issue the row stores and residual loads win; 128x64 beats 128x128
     // (profiles/r01/h_tile_128x64w8.txt: res2*_branch2c 0.41-0.43 -> 0.37-0.38 ms, res3*_branch2c 0.31 -> 0.28 ms)
-    if (K <= 128 && M >= 150000) return shortk;
+    if (K <= 128 && M >= 150000) return kn.shortk;
     if (M >= 150000) return TILE_64x128;
     return TILE_64x64;
 }
 
-int pick_tile_bf16(int M, int N) {
-    static int force = -2;
-    if (force == -2) {
-        const char* e = getenv("HPE_TILE_BF16");
-        force = e ? atoi(e) : -1;
-    }
+int pick_tile_bf16(const TileKnobs& kn, int M, int N) {
     if (N <= 64) return TILE_128x64;
-    if (force >= 0) return force;
+    if (kn.force_bf16 >= 0) return kn.force_bf16;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     return t128 >= 512 ? TILE_128x128 : TILE_64x128;
 }
@@ -238,7 +231,6 @@ int pick_tile_bf16(int M, int N) {
     } while (0)
 
 // one conv layer (+BN fold, +residual, +ReLU) through the implicit-GEMM kernel
-enum { CONV_OUT_SLAB8 = 1, CONV_IN_SLAB8 = 2 };
 
 // the 3x3 layer idx runs as the fused Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
 bool use_wino_fused(const hpe_ctx* c, int idx, int B) {
@@ -246,6 +238,8 @@ bool use_wino_fused(const hpe_ctx* c, int idx, int B) {
     return c->wino_fused && !c->bf16 && c->conv[idx].wino_u && s.kh == 3 && s.stride == 1 && s.hin >= c->wino_fused_min_hw &&
            hpe_wino_fused_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
 }
+
+enum { CONV_OUT_SLAB8 = 1, CONV_IN_SLAB8 = 2, CONV_CONCURRENT = 4 };
 
 hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res, int relu, float* y, hipStream_t st,
                     float* wino_v = nullptr, int slot = 0, int flags = 0) {
@@ -265,6 +259,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
             sk.epoch = ++c->wino_epoch;
             if (sk.epoch == 0) sk.epoch = ++c->wino_epoch;
             sk.n_wg = c->n_cu;
+            sk.err = c->dev_err;
         }
         return hpe_launch_wino_conv3(x, s.cin, L.wino_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v,
                                      c->wino_ws ? &sk : nullptr, st);
@@ -292,7 +287,9 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     p.lda = s.cin;
     p.zero = c->zeros;
     p.y_slab8 = (flags & CONV_OUT_SLAB8) ? 1 : 0;
-    if (B < 64) {  // chunk streams are off below 64 images, so one workspace is enough
+    // The ctx has ONE split-K workspace: only a launch that is alone on the device may use it.  Batch chunks running on
+    // concurrent streams (CONV_CONCURRENT) never split K, whatever their size (their grids overlap each other instead).
+    if (!(flags & CONV_CONCURRENT)) {
         p.partial = c->partial;
         p.partial_floats = c->partial_floats;
     }
@@ -311,9 +308,9 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     }
     if (c->bf16) {
         p.cin_slabs = s.cin / 64;
-        return hpe_launch_gemm_bf16(p, mode, pick_tile_bf16(p.M, p.N), st);
+        return hpe_launch_gemm_bf16(p, mode, pick_tile_bf16(c->knobs, p.M, p.N), st);
     }
-    return hpe_launch_gemm(p, mode, pick_tile(p.M, p.N, p.K), st);
+    return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K), st);
 }
 
 hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
@@ -350,7 +347,9 @@ hipError_t timed_conv(hpe_ctx* c, int idx, const float* x, int B, const float* r
 }
 
 // the encoder on images [i0, i0+B) of the batch (all workspace buffers are image-major)
-hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* features, int ldfeat, hipStream_t st, int slot = 0) {
+hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* features, int ldfeat, hipStream_t st, int slot = 0,
+                         bool concurrent = false) {
+    const int cf = concurrent ? CONV_CONCURRENT : 0;
     // all workspace buffers are image-major; in bf16 mode the same allocations hold bf16 elements (half the bytes)
     const int esz = c->bf16 ? 2 : 4;
     auto at = [&](float* base, size_t elems) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elems * esz); };
@@ -368,11 +367,11 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
     float* wv = (c->wino_v && (i0 == 0 || B >= 32)) ? c->wino_v + (size_t)i0 * WINO_V_PITCH : nullptr;
     if (c->bf16) {
         HIPE(hpe_launch_pad_input_bf16(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
-        HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
+        HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st, nullptr, 0, cf));
         HIPE(hpe_launch_maxpool_bf16(SC, cur, B, 112, 64, st));
     } else {
         HIPE(hpe_launch_pad_input(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
-        HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st));
+        HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st, nullptr, 0, cf));
         HIPE(hpe_launch_maxpool(SC, cur, B, 112, 64, st));
     }
     int ci = 1;
@@ -382,15 +381,15 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
             const bool fz = use_wino_fused(c, i2b, B);  // then T1 is channel-slab major and never leaves this pair of launches
-            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, fz ? CONV_OUT_SLAB8 : 0));
-            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot, fz ? CONV_IN_SLAB8 : 0));
+            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, cf | (fz ? CONV_OUT_SLAB8 : 0)));
+            HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot, cf | (fz ? CONV_IN_SLAB8 : 0)));
             const float* res = cur;
             if (first) {
                 // projection shortcut (conv_block), no ReLU before the add
-                HIPE(timed_conv(c, i1, cur, B, nullptr, 0, SC, st));
+                HIPE(timed_conv(c, i1, cur, B, nullptr, 0, SC, st, nullptr, 0, cf));
                 res = SC;
             }
-            HIPE(timed_conv(c, i2c, T2, B, res, 1, nxt, st));
+            HIPE(timed_conv(c, i2c, T2, B, res, 1, nxt, st, nullptr, 0, cf));
             ci += first ? 4 : 3;
             float* t = cur;
             cur = nxt;
@@ -412,10 +411,16 @@ hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features,
     if (nstream > B / 64) nstream = B / 64;
     if (c->timing >= 2 || nstream < 2) nstream = 1;
     if (nstream == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
-    // chunk size: HPE_CHUNK images (default: one chunk per stream); chunks go round-robin over the streams
-    int per = (B + nstream - 1) / nstream;
-    if (c->chunk_images > 0 && c->chunk_images < per) per = c->chunk_images;
-    const int nchunk = (B + per - 1) / per;
+    // chunk size: about HPE_CHUNK images (default: one chunk per stream), never below 64 -- smaller chunks are launch bound
+    //  -- and all chunks of equal size +-1; chunks go round-robin over the streams
+    int nchunk = nstream;
+    if (c->chunk_images > 0) {
+        const int want = c->chunk_images < 64 ? 64 : c->chunk_images;
+        nchunk = B / want;
+        if (nchunk < nstream) nchunk = nstream;
+    }
+    const int per = (B + nchunk - 1) / nchunk;
+    nchunk = (B + per - 1) / per;
     HIPE(hipEventRecord(c->ev_fork, st));
     for (int k = 1; k < nstream; ++k) HIPE(hipStreamWaitEvent(c->aux[k - 1], c->ev_fork, 0));
     for (int k = 0; k < nchunk; ++k) {
@@ -423,7 +428,7 @@ hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features,
         const int n = (i0 + per <= B) ? per : (B - i0);
         const int sid = k % nstream;
         hipStream_t s = (sid == 0) ? st : c->aux[sid - 1];
-        HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s, sid));
+        HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s, sid, true));
     }
     for (int k = 1; k < nstream; ++k) {
         HIPE(hipEventRecord(c->ev_join[k - 1], c->aux[k - 1]));
@@ -448,6 +453,7 @@ enum { NEED_ENC = 1, NEED_REG = 2, NEED_SMPL = 4 };
 
 int check_ready(hpe_ctx* c, int B, int need) {
     if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    if (c->dead) return fail(HPE_ERR_STATE, "hpe_finalize failed on this ctx: destroy it and create a new one");
     if (!c->finalized) return fail(HPE_ERR_STATE, "hpe_finalize() has not been called");
     if (B < 1 || B > c->cfg.max_batch) return fail(HPE_ERR_INVALID, "batch " + std::to_string(B) + " outside [1, max_batch]");
     if ((need & NEED_ENC) && !c->have_encoder) return fail(HPE_ERR_STATE, "encoder weights were not loaded before hpe_finalize");
@@ -460,6 +466,8 @@ int check_ready(hpe_ctx* c, int B, int need) {
 
 #pragma GCC visibility push(default)
 extern "C" {
+
+static void release_device_state(hpe_ctx* c);
 
 const char* hpe_last_error(void) { return g_err.c_str(); }
 const char* hpe_version(void) { return "hpe_hip 0.1 (gfx950)"; }
@@ -504,15 +512,7 @@ int hpe_destroy(hpe_ctx* c) {
     if (!c) return HPE_OK;
     DeviceGuard g(c->cfg.device);
     (void)hipDeviceSynchronize();
-    for (void* p : c->allocs) (void)hipFree(p);
-    if (c->ev_ok) {
-        for (int i = 0; i < c->n_streams - 1; ++i) (void)hipStreamDestroy(c->aux[i]);
-        (void)hipEventDestroy(c->ev_fork);
-        for (auto& e : c->ev_join) (void)hipEventDestroy(e);
-        for (auto& e : c->ev) (void)hipEventDestroy(e);
-        for (auto& e : c->cev0) (void)hipEventDestroy(e);
-        for (auto& e : c->cev1) (void)hipEventDestroy(e);
-    }
+    release_device_state(c);
     delete c;
     return HPE_OK;
 }
@@ -575,9 +575,53 @@ int hpe_load_mean_theta(hpe_ctx* c, const float* mean85) {
     return HPE_OK;
 }
 
+static int finalize_impl(hpe_ctx* c);
+
+// release everything a (possibly partial) hpe_finalize created
+static void release_device_state(hpe_ctx* c) {
+    for (void* p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    for (auto& a : c->aux)
+        if (a) {
+            (void)hipStreamDestroy(a);
+            a = nullptr;
+        }
+    auto kill = [](hipEvent_t& e) {
+        if (e) {
+            (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+    };
+    kill(c->ev_fork);
+    for (auto& e : c->ev_join) kill(e);
+    for (auto& e : c->ev) kill(e);
+    for (auto& e : c->cev0) kill(e);
+    for (auto& e : c->cev1) kill(e);
+    for (auto& e : c->lev0) kill(e);
+    for (auto& e : c->lev1) kill(e);
+    for (auto& e : c->lev_all) kill(e);
+    c->ev_ok = false;
+}
+
 int hpe_finalize(hpe_ctx* c) {
     if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    if (c->dead) return fail(HPE_ERR_STATE, "an earlier hpe_finalize failed: destroy this ctx and create a new one");
     if (c->finalized) return fail(HPE_ERR_STATE, "already finalized");
+    const int rc = finalize_impl(c);
+    if (rc != HPE_OK && rc != HPE_ERR_STATE) {
+        // a device-side failure part-way (out of memory, ...): nothing of the half-built state survives, so a retry cannot
+        // leak it or double-allocate (the thread-local error message of the failing call is kept)
+        const std::string keep = g_err;
+        DeviceGuard g(c->cfg.device);
+        (void)hipDeviceSynchronize();
+        release_device_state(c);
+        c->dead = true;
+        g_err = keep;
+    }
+    return rc;
+}
+
+static int finalize_impl(hpe_ctx* c) {
     {
         int nconv = 0, ndense = 0;
         for (int i = 0; i < HPE_NUM_CONV; ++i) nconv += c->conv[i].loaded ? 1 : 0;
@@ -604,6 +648,16 @@ int hpe_finalize(hpe_ctx* c) {
         c->wino_fused = (e ? atoi(e) : 1) && c->wino_min_c > 0;
         e = getenv("HPE_WINO_FUSED_MINHW");
         c->wino_fused_min_hw = e ? atoi(e) : 28;
+        e = getenv("HPE_TILE_WIDE");
+        c->knobs.force_wide = e ? atoi(e) : -1;
+        e = getenv("HPE_TILE_NARROW");
+        c->knobs.force_narrow = e ? atoi(e) : -1;
+        e = getenv("HPE_SHORTK_TILE");
+        c->knobs.shortk = e ? atoi(e) : TILE_128x64_W8;
+        e = getenv("HPE_TILE_BF16");
+        c->knobs.force_bf16 = e ? atoi(e) : -1;
+        // per-device function attributes (dynamic LDS above 64 KB) of the Winograd kernels
+        HIP_TRY(hpe_wino_init_device());
     }
     // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
     for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {
@@ -776,8 +830,9 @@ int hpe_finalize(hpe_ctx* c) {
                 c->n_cu = prop.multiProcessorCount;
                 if ((rc = dev_alloc(c, &c->wino_ws, (size_t)4 * c->n_cu * HPE_WINO_WS_FLOATS, false))) return rc;
                 float* fl = nullptr;
-                if ((rc = dev_alloc(c, &fl, (size_t)4 * c->n_cu, true))) return rc;
+                if ((rc = dev_alloc(c, &fl, (size_t)4 * c->n_cu + 4, true))) return rc;
                 c->wino_flags = reinterpret_cast<unsigned*>(fl);
+                c->dev_err = c->wino_flags + (size_t)4 * c->n_cu;
             }
         }
         {
@@ -797,6 +852,9 @@ int hpe_finalize(hpe_ctx* c) {
             if ((rc = dev_alloc(c, &c->work.A, Bpad * 288, true))) return rc;
             if ((rc = dev_alloc(c, &c->work.cams, Bpad * 4, true))) return rc;
             if ((rc = dev_alloc(c, &c->work.verts_tmp, B * HPE_NUM_VERTS * 3, false))) return rc;
+            // reprojection-loss workspace for the geometry the path itself produces (config 5); other sizes grow it on demand
+            c->loss_ws_floats = hpe_mesh_loss_ws_floats(c->cfg.max_batch, HPE_IMG_SIZE, HPE_IMG_SIZE, HPE_NUM_VERTS);
+            if ((rc = dev_alloc(c, &c->loss_ws, c->loss_ws_floats, true))) return rc;
         }
         c->work.Bpad = (int)Bpad;
     }
@@ -815,6 +873,9 @@ int hpe_finalize(hpe_ctx* c) {
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->cev0) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->cev1) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->lev0) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->lev1) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->lev_all) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
     HIP_TRY(hipDeviceSynchronize());
     c->finalized = true;
@@ -958,20 +1019,70 @@ int hpe_kp_loss(const float* kp_gt, const float* kp_pred, int B, int K, float* o
     return HPE_OK;
 }
 
+// Loss workspace: sized in hpe_finalize for max_batch images of 224 x 224 and 6890 vertices (what the path produces); any
+// other geometry grows it here -- the one case in which a compute call synchronises (documented in hpe.h).
+static int ensure_loss_ws(hpe_ctx* c, int B, int H, int W, int P) {
+    const size_t need = hpe_mesh_loss_ws_floats(B, H, W, P);
+    if (need <= c->loss_ws_floats) return HPE_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->loss_ws) {
+        for (auto it = c->allocs.begin(); it != c->allocs.end(); ++it)
+            if (*it == c->loss_ws) {
+                c->allocs.erase(it);
+                break;
+            }
+        (void)hipFree(c->loss_ws);
+        c->loss_ws = nullptr;
+        c->loss_ws_floats = 0;
+    }
+    float* p = nullptr;
+    int rc = dev_alloc(c, &p, need, true);
+    if (rc) return rc;
+    c->loss_ws = p;
+    c->loss_ws_floats = need;
+    return HPE_OK;
+}
+
 int hpe_mesh_loss(hpe_ctx* c, const float* seg, const float* verts2d, int B, int H, int W, int P, float* out, void* stream) {
     if (!c) return fail(HPE_ERR_INVALID, "null ctx");
     if (!seg || !verts2d || !out || B < 1 || H < 1 || W < 1 || P < 1) return fail(HPE_ERR_INVALID, "bad argument");
     DeviceGuard g(c->cfg.device);
-    const size_t need = hpe_mesh_loss_ws_floats(B, H, W, P);
-    if (need > c->loss_ws_floats) {  // first use (or a larger problem): grow the workspace -- synchronises once
-        HIP_TRY(hipDeviceSynchronize());
-        float* p = nullptr;
-        int rc = dev_alloc(c, &p, need, true);
-        if (rc) return rc;
-        c->loss_ws = p;
-        c->loss_ws_floats = need;
-    }
+    int rc = ensure_loss_ws(c, B, H, W, P);
+    if (rc) return rc;
     HIP_TRY(hpe_launch_mesh_loss(seg, verts2d, B, H, W, P, c->loss_ws, out, static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_val_losses(hpe_ctx* c, const float* seg, const float* kp_gt, const float* const* kp2d, const float* const* verts2d, int n_stage,
+                   int B, int K, int H, int W, int P, float* out, void* stream) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    if (!kp_gt || !kp2d || !out || n_stage < 1 || n_stage > 16 || B < 1 || K < 1) return fail(HPE_ERR_INVALID, "bad argument");
+    const bool mesh = seg && verts2d;
+    if (mesh && (H < 1 || W < 1 || P < 1)) return fail(HPE_ERR_INVALID, "bad silhouette / vertex geometry");
+    for (int s = 0; s < n_stage; ++s)
+        if (!kp2d[s] || (mesh && !verts2d[s])) return fail(HPE_ERR_INVALID, "null stage pointer");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool tm = c->timing != 0 && c->ev_ok;
+    c->loss_timed_stages = 0;
+    if (tm) HIP_TRY(hipEventRecord(c->lev_all[0], st));
+    if (mesh) {
+        int rc = ensure_loss_ws(c, B, H, W, P);
+        if (rc) return rc;
+        HIP_TRY(hpe_launch_mesh_loss_prepare(seg, B, H, W, P, c->loss_ws, st));
+    }
+    for (int s = 0; s < n_stage; ++s) {
+        HIP_TRY(hpe_launch_kp_loss(kp_gt, kp2d[s], B * K, out + 4 * s, st));  // writes out[4s .. 4s+2]
+        if (mesh)
+            HIP_TRY(hpe_launch_mesh_loss_search(verts2d[s], B, H, W, P, c->loss_ws, out + 4 * s + 3, st, tm ? c->lev0[s] : nullptr,
+                                                tm ? c->lev1[s] : nullptr));
+        else
+            HIP_TRY(hipMemsetAsync(out + 4 * s + 3, 0, sizeof(float), st));
+    }
+    if (tm) {
+        HIP_TRY(hipEventRecord(c->lev_all[1], st));
+        c->loss_timed_stages = mesh ? n_stage : -1;
+    }
     return HPE_OK;
 }
 
@@ -1052,6 +1163,22 @@ int hpe_debug_joint_regress(hpe_ctx* c, const float* X, int n, int use_kp, float
     return HPE_OK;
 }
 
+int hpe_device_status(hpe_ctx* c, void* stream) {
+    if (!c || !c->finalized) return fail(HPE_ERR_STATE, "needs a finalized ctx");
+    DeviceGuard g(c->cfg.device);
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (c->dev_err) {
+        unsigned w = 0;
+        HIP_TRY(hipMemcpy(&w, c->dev_err, sizeof w, hipMemcpyDeviceToHost));
+        if (w) {
+            (void)hipMemset(c->dev_err, 0, sizeof w);
+            return fail(HPE_ERR_HIP, "device error word " + std::to_string(w) +
+                                         ": a stream-K wait of the Winograd GEMM timed out, outputs since the last check are invalid");
+        }
+    }
+    return HPE_OK;
+}
+
 int hpe_enable_timing(hpe_ctx* c, int enable) {
     if (!c) return fail(HPE_ERR_INVALID, "null ctx");
     c->timing = enable;
@@ -1076,6 +1203,21 @@ int hpe_get_timings(hpe_ctx* c, float ms[5]) {
         }
     }
     ms[2] = ms[4] - ms[0];  // regressor + SMPL stages
+    return HPE_OK;
+}
+
+int hpe_get_loss_timings(hpe_ctx* c, float ms[2]) {
+    if (!c || !ms) return fail(HPE_ERR_INVALID, "null argument");
+    if (c->loss_timed_stages == 0) return fail(HPE_ERR_STATE, "no timed hpe_val_losses call recorded (hpe_enable_timing first)");
+    DeviceGuard g(c->cfg.device);
+    HIP_TRY(hipEventSynchronize(c->lev_all[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], c->lev_all[0], c->lev_all[1]));
+    ms[1] = 0.f;
+    for (int s = 0; s < c->loss_timed_stages; ++s) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c->lev0[s], c->lev1[s]));
+        ms[1] += t;
+    }
     return HPE_OK;
 }
 

@@ -32,6 +32,7 @@ hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st);
 // conv_wino.hip: 3x3/s1 SAME convolution as Winograd F(2x2,3x3); U = G g G^T blocked [N/64][C/8][16][2][64][4], V workspace of
 // hpe_wino_v_floats(B, H, W, C) floats; C % 32 == 0, N % 64 == 0
 size_t hpe_wino_v_floats(int B, int H, int W, int C);
+hipError_t hpe_wino_init_device();  // per-device kernel attributes; call with the target device current
 // optional persistent stream-K scheduling of the GEMM: n_wg workgroups (one per CU), ws = n_wg * HPE_WINO_WS_FLOATS floats and
 // flags = n_wg zero-initialised words owned by the launching stream, epoch unique per launch (never 0)
 #define HPE_WINO_WS_FLOATS 65536
@@ -40,6 +41,7 @@ struct WinoStreamK {
     unsigned* flags;
     unsigned epoch;
     int n_wg;
+    unsigned* err;  // device error word (bit 0 set when a wait timed out), may be nullptr
 };
 hipError_t hpe_launch_wino_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy,
                                  int B, int H, int W, int C, int N, int relu, float* V, const WinoStreamK* sk, hipStream_t st);
@@ -104,6 +106,11 @@ hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* 
 size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P);
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
                                 hipStream_t st);
+// the same in two halves: silhouette compaction + bitmap (once per step), then the searches of one vertex set (once per IEF stage)
+hipError_t hpe_launch_mesh_loss_prepare(const float* seg, int B, int H, int W, int P, float* ws, hipStream_t st);
+// (ev_a2b0 / ev_a2b1: optional events recorded around the pixel -> vertex search, the dominant kernel of the loss)
+hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, int P, float* ws, float* out, hipStream_t st,
+                                       hipEvent_t ev_a2b0, hipEvent_t ev_a2b1);
 
 // prepost.hip
 hipError_t hpe_launch_preprocess_u8(const unsigned char* img, int H, int W, int C, int newH, int newW, int start_x, int start_y,

@@ -459,47 +459,81 @@ size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P) {
     return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64 + bitmap_floats + 16;
 }
 
-hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
-                                hipStream_t st) {
+// Workspace layout shared by the two halves of the mesh loss
+struct MeshWs {
+    float* pts;
+    float* partial;
+    int* counts;
+    unsigned long long* bits;
+    int nA, nB, nblk, WW;
+    bool grid_path;
+};
+
+static MeshWs mesh_ws_layout(float* ws, int B, int H, int W, int P) {
+    MeshWs m;
     const int HW = H * W;
-    const int WW = (W + 63) / 64;
-    const bool grid_path = WW <= NN_MAXWW && (size_t)H * WW * 8 <= 64 * 1024;
-    const int nA = (HW + 1023) / 1024, nB = grid_path ? (P + 255) / 256 : (P + 1023) / 1024;
-    const int nblk = (HW + 1023) / 1024 + (P + 255) / 256;  // workspace pitch (>= nA + nB)
-    float* pts = ws;
-    float* partial = pts + (size_t)B * HW * 2;
-    int* counts = reinterpret_cast<int*>(partial + (size_t)B * nblk);
+    m.WW = (W + 63) / 64;
+    m.grid_path = m.WW <= NN_MAXWW && (size_t)H * m.WW * 8 <= 64 * 1024;
+    m.nA = (HW + 1023) / 1024;
+    m.nB = m.grid_path ? (P + 255) / 256 : (P + 1023) / 1024;
+    m.nblk = (HW + 1023) / 1024 + (P + 255) / 256;  // workspace pitch (>= nA + nB)
+    m.pts = ws;
+    m.partial = m.pts + (size_t)B * HW * 2;
+    m.counts = reinterpret_cast<int*>(m.partial + (size_t)B * m.nblk);
     // 8-byte aligned bitmap after the counts
-    size_t off = (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 2;
+    size_t off = (size_t)B * HW * 2 + (size_t)B * m.nblk + (size_t)B + 2;
     off = (off + 1) & ~(size_t)1;
-    unsigned long long* bits = reinterpret_cast<unsigned long long*>(ws + off);
-    hipLaunchKernelGGL(sil_compact_kernel, dim3(B), dim3(256), 0, st, seg, HW, W, pts, counts);
+    m.bits = reinterpret_cast<unsigned long long*>(ws + off);
+    return m;
+}
+
+// Step-invariant half: the ground-truth silhouette does not change between the IEF stages of one step (src/trainer.py:285-296
+// evaluates the loss of every stage against the same seg_gts), so its compaction (tf.where order) and its bitmap are built once.
+hipError_t hpe_launch_mesh_loss_prepare(const float* seg, int B, int H, int W, int P, float* ws, hipStream_t st) {
+    const MeshWs m = mesh_ws_layout(ws, B, H, W, P);
+    const int HW = H * W;
+    hipLaunchKernelGGL(sil_compact_kernel, dim3(B), dim3(256), 0, st, seg, HW, W, m.pts, m.counts);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || !m.grid_path) return e;
+    const long nwords = (long)B * H * m.WW;
+    hipLaunchKernelGGL(sil_bitmap_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, st, seg, H, W, m.WW, m.bits, nwords);
+    return hipGetLastError();
+}
+
+// Per-stage half: both nearest-neighbour searches against the prepared silhouette + the reduction.
+hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, int P, float* ws, float* out, hipStream_t st,
+                                       hipEvent_t ev_a2b0, hipEvent_t ev_a2b1) {
+    const MeshWs m = mesh_ws_layout(ws, B, H, W, P);
+    const int HW = H * W;
     static int a2b_valu = -1;
     if (a2b_valu < 0) {
         const char* e = getenv("HPE_MESH_A2B");  // "valu": the VALU-only search (A/B comparisons)
         a2b_valu = (e && e[0] == 'v') ? 1 : 0;
     }
+    if (ev_a2b0) (void)hipEventRecord(ev_a2b0, st);
     if (a2b_valu)
-        hipLaunchKernelGGL(nn_a2b_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
+        hipLaunchKernelGGL(nn_a2b_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk);
     else
-        hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(nA, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk);
-    e = hipGetLastError();
+        hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (grid_path) {
-        const long nwords = (long)B * H * WW;
-        hipLaunchKernelGGL(sil_bitmap_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, st, seg, H, W, WW, bits, nwords);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(nB, B), dim3(256), (size_t)H * WW * 8, st, bits, counts, v2d, H, W, WW, P, partial,
-                           nblk, nA);
+    if (ev_a2b1) (void)hipEventRecord(ev_a2b1, st);
+    if (m.grid_path) {
+        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(m.nB, B), dim3(256), (size_t)H * m.WW * 8, st, m.bits, m.counts, v2d, H, W, m.WW, P,
+                           m.partial, m.nblk, m.nA);
     } else {
-        hipLaunchKernelGGL(nn_b2a_kernel, dim3(nB, B), dim3(256), 0, st, pts, counts, v2d, HW, P, partial, nblk, nA);
+        hipLaunchKernelGGL(nn_b2a_kernel, dim3(m.nB, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk, m.nA);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // zero-fill is not needed: every partial slot in [0, nA + nB) is written; finish sums exactly those
-    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), (size_t)B * sizeof(float), st, partial, B, nblk, nA + nB, P, out);
+    hipLaunchKernelGGL(mesh_loss_finish_kernel, dim3(1), dim3(256), (size_t)B * sizeof(float), st, m.partial, B, m.nblk, m.nA + m.nB, P, out);
     return hipGetLastError();
+}
+
+hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
+                                hipStream_t st) {
+    hipError_t e = hpe_launch_mesh_loss_prepare(seg, B, H, W, P, ws, st);
+    if (e != hipSuccess) return e;
+    return hpe_launch_mesh_loss_search(v2d, B, H, W, P, ws, out, st, nullptr, nullptr);
 }

@@ -50,7 +50,7 @@ def all_gather_theta(theta_local, world=None):
     import torch
 
     dist = _dist()
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not _force_collectives()):
         return theta_local
     world = dist.get_world_size() if world is None else world
     out = torch.empty((world * theta_local.shape[0],) + tuple(theta_local.shape[1:]), dtype=theta_local.dtype,
@@ -88,9 +88,26 @@ def reduce_kp_loss(parts_local):
     return torch.where(nc[1] > 0, nc[0] / torch.clamp(nc[1], min=1.0), torch.zeros_like(nc[0]))
 
 
-def reduce_losses(parts_local, mesh_local):
-    """reduce_fn for Predictor.val_step: global kp loss (numerator / count reduced separately) and mesh-loss sum."""
-    return reduce_kp_loss(parts_local), (None if mesh_local is None else reduce_sum(mesh_local))
+def reduce_losses(packed_local):
+    """reduce_fn for Predictor.val_step -- the ONE collective of the config-5 losses: `packed_local`
+    [n_stage, 4] holds (kp numerator, kp count, kp loss, mesh loss sum) of the local shard for every IEF stage; the whole
+    block is summed over the ranks in a single all-reduce (12 floats at 3 stages).  kp_reprojection_loss normalises by the
+    GLOBAL visible count, so column 2 is recomputed from the reduced numerator / count (0 if nothing is visible anywhere);
+    the mesh loss is a plain sum over images."""
+    import torch
+
+    dist = _dist()
+    packed = packed_local.clone()
+    if dist.is_initialized() and (dist.get_world_size() > 1 or _force_collectives()):
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    num, cnt = packed[:, 0], packed[:, 1]
+    packed[:, 2] = torch.where(cnt > 0, num / torch.clamp(cnt, min=1.0), torch.zeros_like(num))
+    return packed
+
+
+def _force_collectives():
+    """HPE_FORCE_DIST=1: issue the collectives even in a world of one rank (rehearses the RCCL calls on a 1-GPU box)."""
+    return bool(os.environ.get("HPE_FORCE_DIST"))
 
 
 def reduce_sum(x):
@@ -126,3 +143,10 @@ class ShardedPredictor(object):
         else:
             res["theta_all"] = all_gather_theta(res["theta"])
         return res
+
+    def val_step(self, images, seg_gts, kp2d_gts, presharded=False, **kw):
+        """Predictor.val_step on this rank's shard with the losses reduced over the ranks (one all-reduce per step)."""
+        if not presharded:
+            lo, hi = shard_bounds(images.shape[0], self.rank, self.world)
+            images, seg_gts, kp2d_gts = images[lo:hi], seg_gts[lo:hi], kp2d_gts[lo:hi]
+        return self.predictor.val_step(images, seg_gts, kp2d_gts, reduce_fn=reduce_losses, **kw)

@@ -247,6 +247,34 @@ class HpeEngine(object):
         _lib.check(self.lib.hpe_mesh_loss(self._h, seg.data_ptr(), verts2d.data_ptr(), B, H, W, P, out.data_ptr(), self._stream()))
         return out[0]
 
+    def val_losses(self, kp_gt, kp2d_stages, seg=None, verts2d_stages=None, out=None):
+        """Both reprojection losses of every IEF stage in one call (hpe_val_losses): -> tensor [n_stage, 4] =
+        (kp numerator, kp count, kp loss, mesh loss sum) per stage.  The silhouette-only work is done once per call."""
+        torch = _torch()
+        kp_gt = _require_cuda_tensor(kp_gt, "kp_gt")
+        n = len(kp2d_stages)
+        kp2d = [_require_cuda_tensor(t, "kp2d") for t in kp2d_stages]
+        B, K = kp_gt.shape[0], kp_gt.shape[1]
+        kp_ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in kp2d])
+        H = W = P = 0
+        seg_ptr, v_ptrs, keep = None, None, None
+        if seg is not None and verts2d_stages is not None:
+            seg = _require_cuda_tensor(seg, "seg")
+            keep = [_require_cuda_tensor(t, "verts2d") for t in verts2d_stages]
+            if len(keep) != n or seg.shape[0] != B:
+                raise ValueError("one verts2d tensor per stage and one silhouette per image are needed")
+            H, W, P = seg.shape[1], seg.shape[2], keep[0].shape[1]
+            seg_ptr = seg.data_ptr()
+            v_ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in keep])
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=self.tdev)
+        _lib.check(self.lib.hpe_val_losses(self._h, seg_ptr, kp_gt.data_ptr(), kp_ptrs, v_ptrs, n, B, K, H, W, P, out.data_ptr(), self._stream()))
+        return out
+
+    def check_device(self):
+        """Synchronise the current stream and raise if a kernel flagged an invalid result (hpe_device_status)."""
+        _lib.check(self.lib.hpe_device_status(self._h, self._stream()))
+
     def debug_conv(self, idx, x, residual=None, relu=True):
         s = CONV_SPECS[idx]
         x = _require_cuda_tensor(x, "x")
@@ -265,6 +293,13 @@ class HpeEngine(object):
         _lib.check(self.lib.hpe_debug_joint_regress(self._h, X.data_ptr(), X.shape[0], int(use_kp_regressor), out.data_ptr(), self._stream()))
         return out
 
+    def encoder_kernel_description(self):
+        """The kernel family bench.py's `roofline` block prices (one string per encoder dtype, kept next to the dispatch)."""
+        if self.encoder_dtype == "fp32":
+            return ("conv_gemm_f32_dma_kernel (37 layers) + wino_fused_kernel / wino_input_kernel + wino_gemm_kernel (the 16 3x3 "
+                    "layers as fp32 Winograd F(2x2,3x3)) -- the 53 conv layers of one step, priced at their direct-convolution FLOPs")
+        return "conv_gemm_bf16_dma_kernel -- the 53 conv layers of one step, priced at their algorithmic HBM bytes"
+
     def enable_timing(self, level=1):
         _lib.check(self.lib.hpe_enable_timing(self._h, int(level)))
 
@@ -272,6 +307,11 @@ class HpeEngine(object):
         ms = (C.c_float * 5)()
         _lib.check(self.lib.hpe_get_timings(self._h, ms))
         return dict(encoder_ms=ms[0], conv_ms=ms[1], regress_smpl_ms=ms[2], total_ms=ms[4])
+
+    def loss_timings(self):
+        ms = (C.c_float * 2)()
+        _lib.check(self.lib.hpe_get_loss_timings(self._h, ms))
+        return dict(val_losses_ms=ms[0], a2b_search_ms=ms[1])
 
     def conv_timings(self):
         ms = (C.c_float * _lib.NUM_CONV)()

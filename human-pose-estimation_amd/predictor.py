@@ -163,11 +163,11 @@ class Predictor(object):
         ``Trainer.val_step`` (src/trainer.py:226-348; BASELINE config 5): per stage
         ``kpr = 60 * kp_reprojection_loss(kp2d_gts, proj_fn(joints, cams))`` (:274-281) and
         ``mr = 0.001 * mesh_reprojection_loss(where(seg > 0), reproject_vertices(verts, cams, [224, 224]), B)``
-        (:285-296).  ``reduce_fn(parts, mesh)`` (see distributed.py) lets ranks reduce the kp (numerator, count)
-        and the mesh sum before the division; default is single-process."""
+        (:285-296).  All stages' (kp numerator, kp count, kp loss, mesh sum) come back from ONE library call
+        (``hpe_val_losses``: the silhouette-only work is done once per step) as a ``[n_stage, 4]`` tensor;
+        ``reduce_fn(packed) -> packed`` (``distributed.reduce_losses``) lets ranks sum that block in a single all-reduce
+        before the kp division; default is single-process."""
         import torch
-
-        from .ops import kp_reprojection_loss
 
         images = self._to_device(images)
         seg = self._to_device(seg_gts)
@@ -180,22 +180,16 @@ class Predictor(object):
             raise ValueError("val_step needs B <= config.batch_size")
         want = ("verts", "joints", "cams", "theta", "kp2d") + (("verts2d",) if use_mesh_repro_loss else ())
         stages = self.engine.forward(images, all_stages=True, want=want)
-        kpr, mr = [], []
-        for st in stages:
-            parts = kp_reprojection_loss(kp_gt, st["kp2d"], return_parts=True)
-            mesh = self.engine.mesh_loss(seg, st["verts2d"]) if use_mesh_repro_loss else None
-            if reduce_fn is not None:
-                loss_kp, mesh = reduce_fn(parts, mesh)
-            else:
-                loss_kp = parts[2]
-            kpr.append(loss_kp * kpr_loss_weight)
-            if use_mesh_repro_loss:
-                mr.append(mesh * mr_loss_weight)
+        packed = self.engine.val_losses(kp_gt, [st["kp2d"] for st in stages], seg if use_mesh_repro_loss else None,
+                                        [st["verts2d"] for st in stages] if use_mesh_repro_loss else None)
+        if reduce_fn is not None:
+            packed = reduce_fn(packed)
+        kpr = [packed[i, 2] * kpr_loss_weight for i in range(len(stages))]
         result = {"kpr_losses": kpr, "pred_keypoints": torch.stack([s["kp2d"] for s in stages], 1),
                   "generated_verts": torch.stack([s["verts"] for s in stages], 1),
-                  "generated_cams": torch.stack([s["cams"] for s in stages], 1)}
+                  "generated_cams": torch.stack([s["cams"] for s in stages], 1), "loss_parts": packed}
         if use_mesh_repro_loss:
-            result["mr_losses"] = mr
+            result["mr_losses"] = [packed[i, 3] * mr_loss_weight for i in range(len(stages))]
         return result
 
     def predict_single_image(self, image):

@@ -14,7 +14,12 @@
  *   - "host" pointers are read during the call and not retained; "dev" pointers are HIP device
  *     pointers owned by the caller (e.g. torch tensors' data_ptr()).  All tensors are dense float32.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  No call synchronises the
- *     device except hpe_create / hpe_load_* / hpe_finalize / hpe_destroy / hpe_get_timings.
+ *     device except hpe_create / hpe_load_* / hpe_finalize / hpe_destroy / hpe_get_timings / hpe_device_status,
+ *     and hpe_mesh_loss / hpe_val_losses ONCE when they meet a problem larger than the loss workspace
+ *     hpe_finalize sized (max_batch images of 224 x 224, 6890 vertices): that call synchronises, frees the
+ *     old workspace and allocates the larger one (such a call cannot be captured into a hipGraph).
+ *   - a hpe_finalize that fails on the device (e.g. out of memory) releases everything it had allocated
+ *     and leaves the ctx dead: every later call returns HPE_ERR_STATE, only hpe_destroy is valid.
  *   - one ctx per device; a ctx is not re-entrant (the reference is not either: SMPL.J_transformed is
  *     mutated per call, src/tf_smpl/batch_smpl.py:135).
  *   - theta layout (kept from the reference, src/predictor.py:136-138):
@@ -137,6 +142,15 @@ int hpe_kp_loss(const float* kp_gt_dev, const float* kp_pred_dev, int B, int K, 
 int hpe_mesh_loss(hpe_ctx* ctx, const float* seg_dev, const float* verts2d_dev, int B, int H, int W, int P, float* out_dev,
                   void* stream);
 
+/* Both reprojection losses of all n_stage IEF stages in ONE call -- what Trainer.val_step evaluates per step
+ * (src/trainer.py:274-296): the work that depends only on seg_gts (tf.where compaction, src/trainer.py:291;
+ * the silhouette bitmap) is done once per call instead of once per stage.
+ * kp2d_dev[i] [B,K,2] and verts2d_dev[i] [B,P,2] are host arrays of n_stage device pointers; seg_dev /
+ * verts2d_dev may be NULL (keypoint loss only).  out_dev [n_stage][4] = {kp numerator, kp count, kp loss,
+ * mesh loss sum}: a rank all-reduces the whole [n_stage][4] block once and re-divides column 0 by column 1. */
+int hpe_val_losses(hpe_ctx* ctx, const float* seg_dev, const float* kp_gt_dev, const float* const* kp2d_dev,
+                   const float* const* verts2d_dev, int n_stage, int B, int K, int H, int W, int P, float* out_dev, void* stream);
+
 /* -- the steps right before / after the path -------------------------- */
 /* preprocess_image (preview.py:18-35) = resize_img + scale_and_crop (src/util/image.py:7-39) + [-1,1] normalisation,
  * fused: img_dev uint8 [H,W,C] (C = 3 or 4, RGB first) -> out224_dev float [224,224,3].
@@ -173,7 +187,13 @@ int hpe_debug_joint_regress(hpe_ctx* ctx, const float* X_dev, int n, int use_kp_
  *   ms[0] encoder (pad + 53 convs + pools), ms[1] sum over the 53 conv launches (level 2, else 0),
  *   ms[2] regressor + SMPL stages, ms[3] reserved (0), ms[4] whole call. */
 int hpe_enable_timing(hpe_ctx* ctx, int level);
+/* Synchronises `stream` and reports the ctx's device error word: HPE_ERR_HIP if a kernel flagged an invalid result since
+ * the last check (today only the opt-in HPE_WINO_STREAMK path can: a bounded inter-workgroup wait that timed out). */
+int hpe_device_status(hpe_ctx* ctx, void* stream);
 int hpe_get_timings(hpe_ctx* ctx, float ms[5]);
+/* last timed hpe_val_losses call: ms[0] = whole call, ms[1] = sum over the stages of the pixel -> nearest-vertex search
+ * (nn_a2b_mfma_kernel, the dominant kernel of the mesh loss) */
+int hpe_get_loss_timings(hpe_ctx* ctx, float ms[2]);
 /* per-conv-layer milliseconds of the last level-2 timed call: ms53[HPE_NUM_CONV] */
 int hpe_get_conv_timings(hpe_ctx* ctx, float* ms53);
 

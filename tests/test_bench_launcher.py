@@ -1,0 +1,34 @@
+"""bench.py's rank launcher without a GPU: `python bench.py --gpus N` must start N rank processes itself (the parent makes
+no HIP call), and a failing rank must make the whole command fail without a JSON line.  Here every rank fails for lack of a
+device, which is exactly the failure path; the success path runs on the GPU box (tests/test_gpu_dist.py)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_launcher_propagates_rank_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("needs a box without a GPU (the GPU-box counterpart is tests/test_gpu_dist.py)")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
+                        "--cpu-sample", "0", "--sustain", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank" in r.stderr and "exited with code" in r.stderr
+
+
+def test_launcher_is_bypassed_under_a_launcher_env():
+    """With RANK / WORLD_SIZE already in the environment (torchrun) nothing is spawned: the process is a rank itself and
+    rejects a world size that does not match --gpus before any device work."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=4 does not match --gpus 2" in r.stderr

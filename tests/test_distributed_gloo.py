@@ -54,7 +54,21 @@ def _worker(rank, world, port, n_global, out_dir):
     cnt = float(2 * np.count_nonzero(vis))
     loss = D.reduce_kp_loss(torch.tensor([num, cnt, 0.0], dtype=torch.float64))
     total = D.reduce_sum(torch.tensor([float(hi - lo)]))
+    # the config-5 block of all stages: ONE all-reduce of [n_stage, 4] = (kp numerator, kp count, kp loss, mesh sum)
+    packed_local = torch.tensor([[num * (s + 1), cnt, -1.0, float(rank + 1) * (s + 1)] for s in range(3)], dtype=torch.float64)
+    n_calls = [0]
+    real = torch.distributed.all_reduce
+
+    def counting(*a, **k):
+        n_calls[0] += 1
+        return real(*a, **k)
+
+    torch.distributed.all_reduce = counting
+    packed = D.reduce_losses(packed_local)
+    torch.distributed.all_reduce = real
+    assert n_calls[0] == 1, n_calls
     if rank == 0:
+        np.save(os.path.join(out_dir, "packed.npy"), packed.numpy())
         np.save(os.path.join(out_dir, "theta_all.npy"), theta_all.numpy())
         np.save(os.path.join(out_dir, "kp_loss.npy"), np.array([float(loss), float(total)]))
     torch.distributed.barrier()
@@ -83,6 +97,10 @@ def test_world2_gather_and_loss_reduce(tmp_path, n_global):
     ref = O.kp_reprojection_loss(kp_gt, pred)
     loss, total = np.load(tmp_path / "kp_loss.npy")
     assert abs(loss - ref) < 1e-6 and total == n_global
+    packed = np.load(tmp_path / "packed.npy")
+    for s in range(3):
+        assert abs(packed[s, 2] - (s + 1) * ref) < 1e-5       # numerator and count reduced separately, divided afterwards
+        assert packed[s, 3] == 3.0 * (s + 1)                   # mesh sums of ranks 0 and 1: (1 + 2) * (s + 1)
 
 
 def test_shard_bounds_cover_everything():

@@ -23,6 +23,14 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def rel_rms(a, b):
+    """max error over the tensor's OWN scale (its RMS): holds small-magnitude outputs (kp2d near 0, cams) to the same bar
+    instead of letting a large entry elsewhere in the tensor set the scale."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.sqrt(np.mean(b * b)) + 1e-30))
+
+
 def gpu(x):
     import torch
 
@@ -264,6 +272,7 @@ def test_winograd_streamk_matches_direct(assets):
             x = np.maximum(g.normal(0, 1, (B, s.hin, s.hin, s.cin)), 0).astype(np.float32)
             for _ in range(3):  # repeated launches: a new epoch each time on the same flags
                 y = e.debug_conv(idx, gpu(x), relu=True)
+            e.check_device()  # raises if a stream-K wait timed out (device error word)
             ys.append(cpu(y))
         outs.append(ys)
         e.close()
@@ -327,6 +336,10 @@ def test_full_path_matches_oracle(engine, assets, B):
         assert rel(cpu(stages[i]["joints"]), ref["stage_joints"][i]) < TOL
         assert rel(cpu(stages[i]["kp2d"]), ref["stage_kp2d"][i]) < TOL
         assert rel(cpu(stages[i]["J_transformed"]), ref["stage_J_transformed"][i]) < TOL
+        # per-output own-scale gates: kp2d and the camera are small-magnitude tensors
+        assert rel_rms(cpu(stages[i]["kp2d"]), ref["stage_kp2d"][i]) < TOL
+        assert rel_rms(cpu(stages[i]["cams"]), ref["stage_cams"][i]) < TOL
+        assert rel_rms(cpu(stages[i]["theta"])[:, 3:75], ref["stage_theta"][i][:, 3:75]) < TOL
     last = engine.forward(gpu(img))[0]
     for k in ("verts", "joints", "cams", "theta", "kp2d"):
         np.testing.assert_array_equal(cpu(last[k]), cpu(stages[2][k]))
@@ -463,8 +476,8 @@ def test_bf16_encoder_variant(assets):
     f32 = O.resnet50_features(img, assets["enc"]).astype(np.float64)
     l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     print("bf16 encoder: rel-L2 vs bf16-emulating oracle %.3g, vs fp32 oracle %.3g (emulation vs fp32 %.3g)" % (l2(f, emu), l2(f, f32), l2(emu, f32)))
-    assert l2(f, emu) < 1e-2
-    assert l2(f, f32) < 3e-2
+    assert l2(f, emu) < 3e-3   # measured 1.2e-3: same rounding points, different summation order
+    assert l2(f, f32) < 1e-2   # measured 2.9e-3: what bf16 activations / weights cost against the fp32 path
     out = eng.forward(gpu(img))[0]
     ref = O.predict(img, assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"])
     mpjpe = float(np.linalg.norm(cpu(out["joints"]) - ref["generated_joints"], axis=-1).mean())
@@ -479,36 +492,45 @@ def test_bf16_encoder_variant(assets):
 
 
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
-def test_full_size_batch_invariance_and_linearity(assets):
-    """BASELINE full size (256 images / GPU): the oracle is too slow there, so check size-independent properties:
-    (1) images are independent units -- rows of a 256-batch equal the same images run in a batch of 2 (up to fp32
+@pytest.mark.parametrize("B", [64, 256])
+def test_full_size_batch_invariance_and_linearity(assets, B):
+    """BASELINE full sizes -- configs[1] as written (64 images: ONE chunk, Winograd only where a launch has >= 128 work
+    items, direct + split-K elsewhere) and the metric batch (256 images / GPU: 3 chunk streams).  The oracle is too slow
+    for whole batches there, so check size-independent properties:
+    (1) images are independent units -- rows of the big batch equal the same images run in a batch of 2 (up to fp32
         summation order: small grids are cut along K and reduced in a fixed order, large ones are not);
-    (2) SMPL at theta = 0 is affine in beta: verts(b1 + b2) + verts(0) == verts(b1) + verts(b2)."""
+    (2) two rows of the big batch against the oracle itself (first and last image);
+    (3) SMPL at theta = 0 is affine in beta: verts(b1 + b2) + verts(0) == verts(b1) + verts(b2)."""
     import torch
 
-    eng = hpe_amd.HpeEngine(device=0, max_batch=256)
+    eng = hpe_amd.HpeEngine(device=0, max_batch=B)
     eng.load_smpl(assets["smpl"])
     eng.load_encoder(assets["enc"])
     eng.load_regressor(assets["reg"])
     eng.load_mean_theta(assets["mean_var"])
     eng.finalize()
-    img = torch.from_numpy(synthetic.make_images(256, seed=555)).cuda()
+    img = torch.from_numpy(synthetic.make_images(B, seed=555)).cuda()
     big = eng.forward(img, all_stages=True)
-    pick = [0, 129, 255]
+    pick = [0, B // 2 + 1, B - 1]
     small = eng.forward(img[pick[1:]].contiguous(), all_stages=True)
     for st in range(3):
         for k in ("theta", "verts", "joints", "kp2d"):
             a = cpu(big[st][k])[pick[1:]]
             b = cpu(small[st][k])
-            assert rel(a, b) < TOL, (st, k)  # different K-summation orders at B=256 and B=2; well inside the 1e-4 bar
-    ref = O.predict(cpu(img[:1]), assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"])
-    assert rel(cpu(big[2]["verts"])[:1], ref["generated_verts"]) < TOL
+            assert rel(a, b) < TOL, (st, k)  # different K-summation orders at B and B=2; well inside the 1e-4 bar
+        assert rel_rms(cpu(big[st]["kp2d"])[pick[1:]], cpu(small[st]["kp2d"])) < TOL
+    rows = [0, B - 1]
+    ref = O.predict(cpu(img[rows]), assets["enc"], assets["reg"], assets["osmpl"], assets["mean_var"])
+    for k, rk in (("verts", "generated_verts"), ("joints", "generated_joints"), ("theta", "theta"), ("kp2d", "generated_kp2d")):
+        assert rel(cpu(big[2][k])[rows], ref[rk]) < TOL, k
+    assert rel_rms(cpu(big[2]["kp2d"])[rows], ref["generated_kp2d"]) < TOL
+    assert rel_rms(cpu(big[2]["cams"])[rows], ref["generated_cams"]) < TOL
     g = np.random.Generator(np.random.Philox(31))
-    b1 = g.normal(0, 1, (256, 10)).astype(np.float32)
-    b2 = g.normal(0, 1, (256, 10)).astype(np.float32)
+    b1 = g.normal(0, 1, (B, 10)).astype(np.float32)
+    b2 = g.normal(0, 1, (B, 10)).astype(np.float32)
 
     def verts_of(beta):
-        th = np.zeros((256, 85), np.float32)
+        th = np.zeros((B, 85), np.float32)
         th[:, 75:] = beta
         return cpu(eng.smpl(gpu(th), want=("verts",))["verts"]).astype(np.float64)
 
@@ -516,6 +538,80 @@ def test_full_size_batch_invariance_and_linearity(assets):
     rhs = verts_of(b1) + verts_of(b2)
     assert rel(lhs, rhs) < 2e-6
     eng.close()
+
+
+def _engine_with_env(assets, env, max_batch, encoder_only=True, **kw):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = hpe_amd.HpeEngine(device=0, max_batch=max_batch, **kw)
+        e.load_encoder(assets["enc"])
+        if not encoder_only:
+            e.load_smpl(assets["smpl"])
+            e.load_regressor(assets["reg"])
+            e.load_mean_theta(assets["mean_var"])
+        e.finalize()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return e
+
+
+def test_chunk_knob_is_clamped_and_race_free(assets):
+    """HPE_CHUNK below 64 used to let 16-image chunks on 3 streams share the single split-K workspace: the
+    knob is now clamped to >= 64 images per chunk and chunked launches never split K.  B = 130 with HPE_CHUNK=16 must
+    reproduce the unchunked (HPE_STREAMS=1) features bit for bit over repeated runs -- both take whole-tile launches."""
+    img = gpu(synthetic.make_images(130, seed=98))
+    base = _engine_with_env(assets, {"HPE_STREAMS": "1"}, 130)
+    f0 = cpu(base.encoder(img))
+    base.close()
+    e = _engine_with_env(assets, {"HPE_CHUNK": "16"}, 130)
+    for _ in range(3):
+        f = cpu(e.encoder(img))
+        assert rel(f, f0) < 2e-5  # a race on the workspace would be O(1)
+    e.close()
+
+
+def test_bf16_full_size_batch_invariance(assets):
+    """bf16 encoder at the metric batch (configs[3]: 256 images, 3 chunk streams): rows equal the same images run in a
+    batch of 2 up to fp32 accumulation order; the regressor / SMPL downstream are fp32."""
+    import torch
+
+    eng = _engine_with_env(assets, {}, 256, encoder_only=False, encoder_dtype="bf16")
+    img = torch.from_numpy(synthetic.make_images(256, seed=556)).cuda()
+    big = eng.forward(img, all_stages=True)
+    pick = [3, 130, 255]
+    small = eng.forward(img[pick].contiguous(), all_stages=True)
+    fb = cpu(eng.encoder(img))[pick]
+    fs = cpu(eng.encoder(img[pick].contiguous()))
+    l2 = float(np.linalg.norm(fb - fs) / np.linalg.norm(fs))
+    print("bf16 features, B=256 rows vs B=3: rel-L2 %.3g" % l2)
+    assert l2 < 1e-3  # one bf16 rounding flips where fp32 sums differ in the last bit
+    for st in range(3):
+        for k in ("theta", "verts", "joints"):
+            assert rel(cpu(big[st][k])[pick], cpu(small[st][k])) < 2e-3, (st, k)
+    eng.close()
+
+
+def test_val_losses_one_call_matches_per_stage_calls(engine, assets):
+    """hpe_val_losses (silhouette work hoisted out of the stages) against the per-stage entry points, bit for bit."""
+    B = 3
+    seg, kp_gt = synthetic.make_lsp_targets(B, seed=19)
+    g = np.random.Generator(np.random.Philox(20))
+    kp2d = [gpu(g.uniform(-1, 1, (B, 19, 2))) for _ in range(3)]
+    v2d = [gpu(g.uniform(20, 200, (B, 6890, 2))) for _ in range(3)]
+    packed = cpu(engine.val_losses(gpu(kp_gt), kp2d, gpu(seg[..., 0]), v2d))
+    for i in range(3):
+        parts = cpu(hpe_amd.kp_reprojection_loss(gpu(kp_gt), kp2d[i], return_parts=True))
+        np.testing.assert_array_equal(packed[i, :3], parts)
+        mesh = float(cpu(hpe_amd.mesh_reprojection_loss(engine, gpu(seg), v2d[i])))
+        assert packed[i, 3] == mesh
+    only_kp = cpu(engine.val_losses(gpu(kp_gt), kp2d))
+    np.testing.assert_array_equal(only_kp[:, :3], packed[:, :3])
+    assert (only_kp[:, 3] == 0).all()
 
 
 # ------------------------------------------------------------------------------------------- asset ingestion from files (SURVEY §8(f) row 1)
