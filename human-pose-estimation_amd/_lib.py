@@ -80,6 +80,7 @@ _PROTOS = {
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_device_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpe_debug_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hpe_debug_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_debug_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_debug_set_dbg": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpe_debug_maxpool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

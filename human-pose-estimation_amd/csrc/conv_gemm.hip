@@ -55,7 +55,7 @@ __device__ __forceinline__ RowAddr make_row(const GemmArgs& p, int m, int kc4) {
     RowAddr r;
     r.mask = 0x1ffu;
     if (m >= p.M) m = p.M - 1;  // tail rows: read a valid row, the store guard drops the result
-    if (MODE == GEMM_DENSE) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_DUAL) {
         r.base = m * p.lda + kc4;
     } else {
         const int hw = p.Ho * p.Wo;
@@ -90,7 +90,7 @@ struct SlabPos {
 
 template <int MODE>
 __device__ __forceinline__ void slab_advance(const GemmArgs& p, SlabPos& sp) {
-    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED || MODE == GEMM_DUAL) {
         sp.off += BK;
     } else if (MODE == GEMM_CONV3) {
         sp.cs += 1;
@@ -120,7 +120,7 @@ __device__ __forceinline__ SlabPos slab_seek(const GemmArgs& p, int slab) {
     SlabPos sp;
     sp.tap = 0;
     sp.cs = 0;
-    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED || MODE == GEMM_DUAL) {
         sp.off = slab * BK;
     } else if (MODE == GEMM_CONV3) {
         sp.tap = slab / p.cin_slabs;
@@ -600,12 +600,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
     // ---- DMA sources: instruction i of wave w fills rows (4i + w) * 8 + (lane >> 3), LDS chunk lane & 7
     const int drow = lane >> 3;
     RowAddr arow[AP];
+    int arow2[MODE == GEMM_DUAL ? AP : 1];  // GEMM_DUAL: the same rows in the second (strided) source
     const float* wsrc[BP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int r = (NW * i + wave) * 8 + drow;
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
         arow[i] = make_row<MODE>(p, m0 + r, lc * 4);
+        if (MODE == GEMM_DUAL) arow2[i] = make_row<GEMM_STRIDED>(p, m0 + r, lc * 4).base;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -647,6 +649,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
             if (MODE == GEMM_CONV3) {
                 const bool ok = (arow[i].mask >> sp.tap) & 1u;
                 src = ok ? (p.x + (arow[i].base + sp.off)) : p.zero;
+            } else if (MODE == GEMM_DUAL) {
+                // wave-uniform choice of the source by the absolute slab index (also right inside a split-K slice)
+                src = slab < p.k1_slabs ? p.x + (arow[i].base + slab * BK) : p.x2 + (arow2[i] + (slab - p.k1_slabs) * BK);
             } else {
                 src = p.x + (arow[i].base + sp.off);
             }
@@ -785,7 +790,7 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
         hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(512), 0, st, p);
         return hipGetLastError();
     } else {
-    if (stage_variant() == 1 && p.zero) {
+    if ((stage_variant() == 1 && p.zero) || MODE == GEMM_DUAL) {
         // latency-bound small grids: cut K so that about one workgroup per CU runs (>= 4 slabs per slice)
         const int S = p.K / BK;
         if (p.partial && splitk_enabled() && grid < 128 && S >= 8) {
@@ -801,6 +806,8 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
         hipLaunchKernelGGL((conv_gemm_fixup_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), 0, st, p);
         return hipGetLastError();
     }
+    if constexpr (MODE == GEMM_DUAL) return hipErrorInvalidValue;  // (not reached: the dual-source mode is LDS-DMA only)
+    else
     switch (sched_variant()) {
         case 1: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 1>), dim3(grid), dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL((conv_gemm_f32_kernel<MODE, BM, BN, WM, WN, 2>), dim3(grid), dim3(256), 0, st, p); break;
@@ -862,6 +869,12 @@ hipError_t hpe_launch_gemm(GemmArgs p, int mode, int tile, hipStream_t st) {
         case GEMM_STEM:
             if (p.K != 7 * BK || p.Hi < 2 * (p.Ho - 1) + 7 || p.Wi < 2 * (p.Wo - 1) + 8) return hipErrorInvalidValue;
             return launch_mode<GEMM_STEM>(p, tile, st);
+        case GEMM_DUAL:
+            if (!p.x2 || ((uintptr_t)p.x2 & 15) != 0 || p.k1_slabs < 1 || p.k1_slabs * BK >= p.K || p.lda < p.k1_slabs * BK || (p.lda % 4) != 0)
+                return hipErrorInvalidValue;
+            if (p.Cin != p.K - p.k1_slabs * BK || (p.Cin % 4) != 0 || p.M != (p.M / (p.Ho * p.Wo)) * p.Ho * p.Wo) return hipErrorInvalidValue;
+            if ((p.Ho - 1) * p.stride >= p.Hi || (p.Wo - 1) * p.stride >= p.Wi) return hipErrorInvalidValue;
+            return launch_mode<GEMM_DUAL>(p, tile, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -29,7 +29,7 @@ __device__ __forceinline__ RowB make_row_b(const GemmArgs& p, int m, int lc) {
     RowB r;
     r.mask = 0x1ffu;
     if (m >= p.M) m = p.M - 1;
-    if (MODE == GEMM_DENSE) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_DUAL) {
         r.base = m * p.lda + lc * 8;
     } else {
         const int hw = p.Ho * p.Wo;
@@ -62,7 +62,7 @@ struct SlabB {
 
 template <int MODE>
 __device__ __forceinline__ void slab_advance_b(const GemmArgs& p, SlabB& sp) {
-    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED) {
+    if (MODE == GEMM_DENSE || MODE == GEMM_STRIDED || MODE == GEMM_DUAL) {
         sp.off += BKE;
     } else if (MODE == GEMM_CONV3) {
         sp.cs += 1;
@@ -117,12 +117,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dm
 
     const int drow = lane >> 3;
     RowB arow[AP];
+    int arow2[MODE == GEMM_DUAL ? AP : 1];  // GEMM_DUAL: the same rows in the second (strided) source
+    const __bf16* X2 = reinterpret_cast<const __bf16*>(p.x2);
     const __bf16* wsrc[BP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int r = (NW * i + wave) * 8 + drow;
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
         arow[i] = make_row_b<MODE>(p, m0 + r, lc);
+        if (MODE == GEMM_DUAL) arow2[i] = make_row_b<GEMM_STRIDED>(p, m0 + r, lc).base;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -167,6 +170,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dm
             if (MODE == GEMM_CONV3) {
                 const bool ok = (arow[i].mask >> sp.tap) & 1u;
                 src = ok ? static_cast<const void*>(X + (arow[i].base + sp.off)) : static_cast<const void*>(p.zero);
+            } else if (MODE == GEMM_DUAL) {
+                src = slab < p.k1_slabs ? X + (arow[i].base + slab * BKE) : X2 + (arow2[i] + (slab - p.k1_slabs) * BKE);
             } else {
                 src = X + (arow[i].base + sp.off);
             }
@@ -395,6 +400,12 @@ hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st) 
         case GEMM_STEM:
             if (p.K != 4 * BKE || p.Hi < 2 * (p.Ho - 1) + 8 || p.Wi < 2 * (p.Wo - 1) + 8) return hipErrorInvalidValue;
             return launch_mode_b<GEMM_STEM>(p, tile, st);
+        case GEMM_DUAL:
+            if (!p.x2 || ((uintptr_t)p.x2 & 15) != 0 || p.k1_slabs < 1 || p.k1_slabs * BKE >= p.K || p.lda < p.k1_slabs * BKE || (p.lda % 8) != 0)
+                return hipErrorInvalidValue;
+            if (p.Cin != p.K - p.k1_slabs * BKE || (p.Cin % 8) != 0 || p.M != (p.M / (p.Ho * p.Wo)) * p.Ho * p.Wo) return hipErrorInvalidValue;
+            if ((p.Ho - 1) * p.stride >= p.Hi || (p.Wo - 1) * p.stride >= p.Wi) return hipErrorInvalidValue;
+            return launch_mode_b<GEMM_DUAL>(p, tile, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -86,6 +86,12 @@ struct ConvLayer {
     float* w = nullptr;  // device, packed [n_pad][k_pad] (fp32) or bf16 [n_pad][k_pad16] in bf16 mode
     float* scale = nullptr;
     float* shift = nullptr;
+    // *_branch2c of a conv_block only: [scale2c * W2c | scale1 * W1] concatenated along k and the summed shifts -- the expand
+    // convolution and the projection shortcut as one dual-source GEMM (GEMM_DUAL)
+    float* w_dual = nullptr;
+    float* shift_dual = nullptr;
+    int k_dual = 0, k1_dual = 0;
+    void* stem_w = nullptr;   // conv1 only: weights in the k enumeration of stem_fused.hip (fp32 [64][160] / bf16 [64][7][32])
     float* wino_u = nullptr;  // device, G g G^T in the blocked layout of conv_wino.hip (3x3 layers on the Winograd path only)
     int n_pad = 0, k_pad = 0;
 };
@@ -160,6 +166,8 @@ struct hpe_ctx {
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     int wino_min_items = 128; // ... when the launch has at least this many workgroups
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
+    int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
+    int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
@@ -313,6 +321,41 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K), st);
 }
 
+// branch2c (+BN) + branch1 (+BN) + add + ReLU of a conv_block as one dual-source GEMM: t2 [M, K1] dense, x NHWC strided
+hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x, int B, float* y, hipStream_t st, int flags) {
+    const ConvSpec& s2 = specs()[i2c];
+    const ConvSpec& s1 = specs()[i1];
+    const ConvLayer& L = c->conv[i2c];
+    const int slab = c->bf16 ? 64 : 32;
+    GemmArgs p{};
+    p.x = t2;
+    p.x2 = x;
+    p.w = L.w_dual;
+    p.scale = c->ones;
+    p.shift = L.shift_dual;
+    p.y = y;
+    p.M = B * s2.hout * s2.hout;
+    p.N = s2.cout;
+    p.K = L.k_dual;
+    p.k1_slabs = L.k1_dual / slab;
+    p.lda = s2.cin;
+    p.ldw = L.k_dual;
+    p.w_rows = round_up(s2.cout, 128);
+    p.ldy = s2.cout;
+    p.relu = 1;
+    p.Hi = p.Wi = s1.hin;
+    p.Cin = s1.cin;
+    p.Ho = p.Wo = s1.hout;
+    p.stride = s1.stride;
+    p.zero = c->zeros;
+    if (!(flags & CONV_CONCURRENT)) {
+        p.partial = c->partial;
+        p.partial_floats = c->partial_floats;
+    }
+    if (c->bf16) return hpe_launch_gemm_bf16(p, GEMM_DUAL, pick_tile_bf16(c->knobs, p.M, p.N), st);
+    return hpe_launch_gemm(p, GEMM_DUAL, pick_tile(c->knobs, p.M, p.N, p.K), st);
+}
+
 hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
                      const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
     GemmArgs p{};
@@ -365,7 +408,14 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
     float* nxt = at(c->X1, o_big);
     // the chunk's slice of the Winograd workspace (chunks of < 32 images only occur unchunked, i0 == 0: the slack at the end covers them)
     float* wv = (c->wino_v && (i0 == 0 || B >= 32)) ? c->wino_v + (size_t)i0 * WINO_V_PITCH : nullptr;
-    if (c->bf16) {
+    if (c->stem_fused) {
+        // conv1_pad .. pool1 in one kernel straight from the caller's images (stem_fused.hip); timed as conv layer 0
+        const bool t2 = c->timing >= 2;
+        if (t2) HIPE(hipEventRecord(c->cev0[0], st));
+        HIPE(hpe_launch_stem_fused(images + o_img, c->conv[0].stem_w, c->conv[0].scale, c->conv[0].shift, cur, B, hpe_stem_fused_pick_rows(B),
+                                   c->bf16 ? 1 : 0, st));
+        if (t2) HIPE(hipEventRecord(c->cev1[0], st));
+    } else if (c->bf16) {
         HIPE(hpe_launch_pad_input_bf16(images + o_img, padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
         HIPE(timed_conv(c, 0, padded, B, nullptr, 1, SC, st, nullptr, 0, cf));
         HIPE(hpe_launch_maxpool_bf16(SC, cur, B, 112, 64, st));
@@ -384,12 +434,24 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
             HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, cf | (fz ? CONV_OUT_SLAB8 : 0)));
             HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot, cf | (fz ? CONV_IN_SLAB8 : 0)));
             const float* res = cur;
-            if (first) {
-                // projection shortcut (conv_block), no ReLU before the add
-                HIPE(timed_conv(c, i1, cur, B, nullptr, 0, SC, st, nullptr, 0, cf));
-                res = SC;
+            if (first && c->conv[i2c].w_dual) {
+                // conv_block: expand convolution + projection shortcut + add + ReLU as one dual-source GEMM (timed as layer i2c)
+                const bool t2 = c->timing >= 2;
+                if (t2) HIPE(hipEventRecord(c->cev0[i2c], st));
+                HIPE(run_dual(c, i2c, i1, T2, cur, B, nxt, st, cf));
+                if (t2) {
+                    HIPE(hipEventRecord(c->cev1[i2c], st));
+                    HIPE(hipEventRecord(c->cev0[i1], st));
+                    HIPE(hipEventRecord(c->cev1[i1], st));
+                }
+            } else {
+                if (first) {
+                    // projection shortcut (conv_block), no ReLU before the add
+                    HIPE(timed_conv(c, i1, cur, B, nullptr, 0, SC, st, nullptr, 0, cf));
+                    res = SC;
+                }
+                HIPE(timed_conv(c, i2c, T2, B, res, 1, nxt, st, nullptr, 0, cf));
             }
-            HIPE(timed_conv(c, i2c, T2, B, res, 1, nxt, st, nullptr, 0, cf));
             ci += first ? 4 : 3;
             float* t = cur;
             cur = nxt;
@@ -656,8 +718,56 @@ static int finalize_impl(hpe_ctx* c) {
         c->knobs.shortk = e ? atoi(e) : TILE_128x64_W8;
         e = getenv("HPE_TILE_BF16");
         c->knobs.force_bf16 = e ? atoi(e) : -1;
-        // per-device function attributes (dynamic LDS above 64 KB) of the Winograd kernels
+        e = getenv("HPE_STEM_FUSED");
+        c->stem_fused = e ? atoi(e) : 1;
+        e = getenv("HPE_DUAL");
+        c->dual_gemm = e ? atoi(e) : 1;
+        // per-device function attributes (dynamic LDS above 64 KB) of the Winograd and stem kernels
         HIP_TRY(hpe_wino_init_device());
+        HIP_TRY(hpe_stem_fused_init_device());
+    }
+    // ---- conv_block (first block of a stage): out = relu(bn2c(W2c . t2) + bn1(W1 . x_strided)).  Both convolutions are 1x1,
+    //      so they are ONE GEMM over the concatenated k axis once each BN scale is folded into its weights:
+    //      out = relu([s2c W2c | s1 W1] . [t2 ; x] + (shift2c + shift1))   -- no shortcut tensor in HBM, one launch instead of two
+    if (c->have_encoder && c->dual_gemm) {
+        int ci = 1;
+        const int nblk[4] = {3, 4, 6, 3};
+        for (int stg = 0; stg < 4; ++stg) {
+            const int i2c = ci + 2, i1 = ci + 3;
+            const ConvSpec& s2 = specs()[i2c];
+            const ConvSpec& s1 = specs()[i1];
+            ConvLayer& L2 = c->conv[i2c];
+            const ConvLayer& L1 = c->conv[i1];
+            const int K1 = s2.cin, K2 = s1.cin, N = s2.cout;
+            const int slab = c->bf16 ? 64 : 32;
+            if (K1 % slab == 0 && K2 % slab == 0) {
+                const int n_pad = round_up(N, 128), K = K1 + K2;
+                std::vector<float> wt((size_t)n_pad * K, 0.f), sh(N);
+                for (int n = 0; n < N; ++n) {
+                    const double inv2 = (double)L2.gamma[n] / std::sqrt((double)L2.var[n] + (double)c->cfg.bn_eps);
+                    const double inv1 = (double)L1.gamma[n] / std::sqrt((double)L1.var[n] + (double)c->cfg.bn_eps);
+                    for (int k = 0; k < K1; ++k) wt[(size_t)n * K + k] = (float)(inv2 * (double)L2.kernel[(size_t)k * N + n]);
+                    for (int k = 0; k < K2; ++k) wt[(size_t)n * K + K1 + k] = (float)(inv1 * (double)L1.kernel[(size_t)k * N + n]);
+                    sh[n] = (float)((((double)L2.bias[n] - (double)L2.mean[n]) * inv2 + (double)L2.beta[n]) +
+                                    (((double)L1.bias[n] - (double)L1.mean[n]) * inv1 + (double)L1.beta[n]));
+                }
+                if (c->bf16) {
+                    std::vector<unsigned short> wb(wt.size());
+                    for (size_t q = 0; q < wt.size(); ++q) wb[q] = f2bf(wt[q]);
+                    void* qd = nullptr;
+                    HIP_TRY(hipMalloc(&qd, wb.size() * 2));
+                    c->allocs.push_back(qd);
+                    HIP_TRY(hipMemcpy(qd, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+                    L2.w_dual = static_cast<float*>(qd);
+                } else {
+                    if ((rc = upload(c, &L2.w_dual, wt))) return rc;
+                }
+                if ((rc = upload(c, &L2.shift_dual, sh))) return rc;
+                L2.k_dual = K;
+                L2.k1_dual = K1;
+            }
+            ci += 4 + 3 * (nblk[stg] - 1);
+        }
     }
     // ---- encoder weights: HWIO -> Wt[n][k] (k = (kh,kw,cin), cin fastest), zero padded; BN -> scale/shift
     for (int i = 0; c->have_encoder && i < HPE_NUM_CONV; ++i) {
@@ -714,6 +824,31 @@ static int finalize_impl(hpe_ctx* c) {
             if ((rc = upload(c, &L.wino_u, U))) return rc;
         }
         }
+        if (i == 0) {  // fused stem: same weights in the k enumeration of stem_fused.hip
+            void* q = nullptr;
+            if (c->bf16) {
+                std::vector<unsigned short> wp((size_t)64 * 7 * 32, 0);
+                for (int kh = 0; kh < 7; ++kh)
+                    for (int kw = 0; kw < 7; ++kw)
+                        for (int ci = 0; ci < 3; ++ci)
+                            for (int n = 0; n < 64; ++n)
+                                wp[((size_t)n * 7 + kh) * 32 + kw * 4 + ci] = f2bf(L.kernel[(((size_t)kh * 7 + kw) * 3 + ci) * 64 + n]);
+                HIP_TRY(hipMalloc(&q, wp.size() * 2));
+                c->allocs.push_back(q);
+                HIP_TRY(hipMemcpy(q, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+            } else {
+                std::vector<float> wp((size_t)64 * 160, 0.f);
+                for (int kh = 0; kh < 7; ++kh)
+                    for (int kw = 0; kw < 7; ++kw)
+                        for (int ci = 0; ci < 3; ++ci)
+                            for (int n = 0; n < 64; ++n)
+                                wp[(size_t)n * 160 + kh * 22 + 1 + kw * 3 + ci] = L.kernel[(((size_t)kh * 7 + kw) * 3 + ci) * 64 + n];
+                HIP_TRY(hipMalloc(&q, wp.size() * 4));
+                c->allocs.push_back(q);
+                HIP_TRY(hipMemcpy(q, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+            }
+            L.stem_w = q;
+        }
         std::vector<float> sc(s.cout), sh(s.cout);
         for (int n = 0; n < s.cout; ++n) {
             const double inv = (double)L.gamma[n] / std::sqrt((double)L.var[n] + (double)c->cfg.bn_eps);
@@ -725,7 +860,7 @@ static int finalize_impl(hpe_ctx* c) {
         std::vector<float>().swap(L.kernel);
     }
     // constants every part uses: the zero page is the LDS-DMA source of out-of-image taps / halo pixels
-    if ((rc = upload(c, &c->ones, std::vector<float>(1024, 1.f)))) return rc;
+    if ((rc = upload(c, &c->ones, std::vector<float>(2048, 1.f)))) return rc;
     if ((rc = upload(c, &c->zeros, std::vector<float>(1024, 0.f)))) return rc;
     // ---- regressor: Dense kernels [in,out] -> [out_pad][in_pad]; W1 split into features / theta parts
     if (c->have_regressor) {
@@ -1106,6 +1241,17 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
         return HPE_OK;
     }
     HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st, c->wino_v));
+    return HPE_OK;
+}
+
+int hpe_debug_stem(hpe_ctx* c, const float* images, int B, int rows_per_strip, float* y, void* stream) {
+    int rc = check_ready(c, B, NEED_ENC);
+    if (rc) return rc;
+    if (!images || !y) return fail(HPE_ERR_INVALID, "null pointer");
+    if (c->bf16) return fail(HPE_ERR_STATE, "hpe_debug_stem works on fp32 contexts only");
+    DeviceGuard g(c->cfg.device);
+    const int R = rows_per_strip > 0 ? rows_per_strip : hpe_stem_fused_pick_rows(B);
+    HIP_TRY(hpe_launch_stem_fused(images, c->conv[0].stem_w, c->conv[0].scale, c->conv[0].shift, y, B, R, 0, static_cast<hipStream_t>(stream)));
     return HPE_OK;
 }
 

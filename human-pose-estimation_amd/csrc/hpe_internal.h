@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-enum GemmMode { GEMM_DENSE = 0, GEMM_STRIDED = 1, GEMM_CONV3 = 2, GEMM_STEM = 3 };
+// GEMM_DUAL: two A sources summed into one accumulator (K concatenated): k-slabs [0, k1_slabs) come from the dense matrix x
+// (row pitch lda), the rest from the strided NHWC tensor x2 (geometry in Hi / Wi / Cin / Ho / Wo / stride) -- the last 1x1
+// convolution of a ResNet conv_block and its projection shortcut as ONE launch (weights concatenated along k, BN scales folded in)
+enum GemmMode { GEMM_DENSE = 0, GEMM_STRIDED = 1, GEMM_CONV3 = 2, GEMM_STEM = 3, GEMM_DUAL = 4 };
 enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3, TILE_128x128_W8 = 4, TILE_128x64_W8 = 5, TILE_256x128_W8 = 6 };
 
 // Arguments of the implicit-GEMM kernel (conv_gemm.hip).  All offsets are in floats.
@@ -24,6 +27,8 @@ struct GemmArgs {
     size_t partial_floats;
     const float* zero;       // >= 16 B of zeros in global memory (source of out-of-image taps for the LDS-DMA path)
     unsigned long long* dbg;  // diagnostics only (HPE_ABLATION builds): per-workgroup {shader clocks, 100 MHz ticks}
+    const float* x2;  // GEMM_DUAL: second A source (strided NHWC)
+    int k1_slabs;     // GEMM_DUAL: k-slabs taken from x
     int y_slab8;  // 1: y is written channel-slab major, y[(n / 8) * M + m][n % 8] (the layout the fused Winograd kernel reads); needs N % 8 == 0
 };
 
@@ -57,6 +62,14 @@ hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st);
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
 hipError_t hpe_launch_maxpool_bf16(const void* x, void* y, int B, int H, int C, hipStream_t st);
 hipError_t hpe_launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, int ldy, hipStream_t st);
+
+// stem_fused.hip: conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + max-pool in one kernel; img [B,224,224,3] fp32 ->
+// y [B,56,56,64] (fp32, or bf16 when bf16 != 0).  w: fp32 [64][160] (k = kh * 22 + 1 + kw * 3 + c, other slots zero) or
+// bf16 [64][7][32] (k = kh * 32 + kw * 4 + c, other slots zero).  R pooled rows per workgroup, 56 % R == 0, R <= 8.
+hipError_t hpe_launch_stem_fused(const float* img, const void* w, const float* scale, const float* shift, void* y, int B, int R, int bf16,
+                                 hipStream_t st);
+hipError_t hpe_stem_fused_init_device();
+int hpe_stem_fused_pick_rows(int B);
 
 // encoder_ops.hip
 hipError_t hpe_launch_pad_input(const float* img, float* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);

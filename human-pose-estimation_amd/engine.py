@@ -286,6 +286,12 @@ class HpeEngine(object):
         _lib.check(self.lib.hpe_debug_conv(self._h, idx, x.data_ptr(), B, r, int(relu), y.data_ptr(), self._stream()))
         return y
 
+    def debug_stem(self, images, rows_per_strip=0):
+        images = _require_cuda_tensor(images, "images", (224, 224, 3))
+        y = self._new(images.shape[0], 56, 56, 64)
+        _lib.check(self.lib.hpe_debug_stem(self._h, images.data_ptr(), images.shape[0], int(rows_per_strip), y.data_ptr(), self._stream()))
+        return y
+
     def joint_regress(self, X, use_kp_regressor=True):
         X = _require_cuda_tensor(X, "X", (NUM_VERTS, 3))
         K = self.num_kp if use_kp_regressor else 24

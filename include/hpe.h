@@ -169,6 +169,10 @@ int hpe_get_original(const float* verts_dev, const float* cam_dev, int B, int P,
  * post-ReLU conv1 output [B,112,112,64]. */
 int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float* residual_dev, int relu, float* y_dev,
                    void* stream);
+/* The fused stem kernel alone (conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + MaxPooling2D(3,2) of the Keras ResNet50,
+ * src/models.py:39): images_dev [B,224,224,3] -> y_dev [B,56,56,64].  rows_per_strip: pooled rows per workgroup
+ * (1, 2, 4, 7 or 8; 0 = the default for this batch).  fp32 contexts only. */
+int hpe_debug_stem(hpe_ctx* ctx, const float* images_dev, int B, int rows_per_strip, float* y_dev, void* stream);
 /* Raw GEMM through the conv kernel (dense mode): y[M,N] = act(x[M,K] . wt[n][k]^T (+ residual)), wt has w_rows >= N
  * rounded up to the tile width rows of K floats; K % 32 == 0; tile: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 64x128. */
 int hpe_debug_gemm(hpe_ctx* ctx, const float* x_dev, const float* wt_dev, int M, int N, int K, int w_rows, int tile,

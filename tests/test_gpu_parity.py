@@ -280,6 +280,63 @@ def test_winograd_streamk_matches_direct(assets):
         assert rel(yw, yd) < 5e-6
 
 
+@pytest.mark.parametrize("R", [0, 1, 2, 4, 7, 8])
+def test_fused_stem_matches_oracle(engine, assets, R):
+    """conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + MaxPooling2D(3,2) in one kernel (stem_fused.hip) against the oracle's
+    own layers in fp64, for every strip height (pooled rows per workgroup; 0 = the default for the batch): strips at the image
+    top / bottom take their zero rows from conv1_pad, inner strips recompute one halo conv row."""
+    import torch
+
+    B = 3
+    img = synthetic.make_images(B, seed=311)
+    img[0, :5, :, :] = 1.0   # strong top / left borders: the padding rows and columns matter
+    img[1, :, :4, :] = -1.0
+    y = cpu(engine.debug_stem(gpu(img), rows_per_strip=R))
+    s = resnet_spec.CONV_SPECS[0]
+    p = assets["enc"]
+    lin = O.conv2d_nhwc(img, p[s.name + "/kernel"], p[s.name + "/bias"], 2, 3, dtype=np.float64)
+    sc, sh = _bn_fold(p, s)
+    act = np.maximum(lin * sc + sh, 0)
+    t = torch.from_numpy(act).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.max_pool2d(torch.nn.functional.pad(t, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1).numpy()
+    assert y.shape == ref.shape == (B, 56, 56, 64)
+    assert rel(y, ref) < 5e-6, R
+
+
+def test_fused_stem_equals_unfused_encoder(assets):
+    """Whole encoder with the fused stem (default) and with pad / im2col GEMM / max-pool kernels (HPE_STEM_FUSED=0)."""
+    img = gpu(synthetic.make_images(5, seed=78))
+    f = []
+    for env in ({"HPE_STEM_FUSED": "0"}, {}):
+        e = _engine_with_env(assets, env, 8)
+        f.append(cpu(e.encoder(img)))
+        e.close()
+    assert rel(f[1], f[0]) < 2e-5
+    ref = O.resnet50_features(cpu(img[:2]), assets["enc"])
+    assert rel(f[1][:2], ref) < TOL
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_dual_source_gemm_equals_two_launches(assets, dtype):
+    """conv_block: branch2c + branch1 (projection shortcut) + add + ReLU as ONE dual-source GEMM (default) against the two
+    launches through the shortcut buffer (HPE_DUAL=0).  The fused form folds each BN scale into its weights, so the two differ
+    by weight rounding only (fp32: ~1e-7 per layer; bf16: one bf16 ulp of a weight)."""
+    img = gpu(synthetic.make_images(5, seed=79))
+    f = []
+    for env in ({"HPE_DUAL": "0"}, {}):
+        e = _engine_with_env(assets, env, 8, encoder_dtype=dtype)
+        f.append(cpu(e.encoder(img)).astype(np.float64))
+        e.close()
+    if dtype == "fp32":
+        assert rel(f[1], f[0]) < 2e-5
+        ref = O.resnet50_features(cpu(img[:2]), assets["enc"])
+        assert rel(f[1][:2], ref) < TOL
+    else:
+        l2 = float(np.linalg.norm(f[1] - f[0]) / np.linalg.norm(f[0]))
+        print("bf16 dual-source vs two launches: rel-L2 %.3g" % l2)
+        assert l2 < 3e-3
+
+
 def test_pools(engine):
     import ctypes as C
 
