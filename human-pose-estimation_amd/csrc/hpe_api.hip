@@ -91,6 +91,7 @@ struct ConvLayer {
     float* w_dual = nullptr;
     float* shift_dual = nullptr;
     int k_dual = 0, k1_dual = 0;
+    void* w_stream = nullptr; // bf16, *_branch2c of identity blocks: weights in the fragment order of conv1x1_stream_bf16.hip
     void* stem_w = nullptr;   // conv1 only: weights in the k enumeration of stem_fused.hip (fp32 [64][160] / bf16 [64][7][32])
     float* wino_u = nullptr;  // device, G g G^T in the blocked layout of conv_wino.hip (3x3 layers on the Winograd path only)
     int n_pad = 0, k_pad = 0;
@@ -166,6 +167,7 @@ struct hpe_ctx {
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     int wino_min_items = 128; // ... when the launch has at least this many workgroups
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
+    int stream_expand = 1;    // bf16: identity-block expand layers through the streaming kernel (HPE_STREAM=0: generic implicit GEMM)
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
@@ -315,6 +317,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         mode = GEMM_STRIDED;
     }
     if (c->bf16) {
+        if (L.w_stream && res) return hpe_launch_conv1x1_stream_bf16(x, L.w_stream, res, y, p.M, p.N, s.cin, relu, st);
         p.cin_slabs = s.cin / 64;
         return hpe_launch_gemm_bf16(p, mode, pick_tile_bf16(c->knobs, p.M, p.N), st);
     }
@@ -722,6 +725,8 @@ static int finalize_impl(hpe_ctx* c) {
         c->stem_fused = e ? atoi(e) : 1;
         e = getenv("HPE_DUAL");
         c->dual_gemm = e ? atoi(e) : 1;
+        e = getenv("HPE_STREAM");
+        c->stream_expand = e ? atoi(e) : 1;
         // per-device function attributes (dynamic LDS above 64 KB) of the Winograd and stem kernels
         HIP_TRY(hpe_wino_init_device());
         HIP_TRY(hpe_stem_fused_init_device());
@@ -857,6 +862,34 @@ static int finalize_impl(hpe_ctx* c) {
         }
         if ((rc = upload(c, &L.scale, sc))) return rc;
         if ((rc = upload(c, &L.shift, sh))) return rc;
+        if (c->bf16 && c->stream_expand && s.kh == 1 && s.stride == 1 && s.cout == 4 * s.cin && hpe_stream_bf16_supported(s.cout, s.cin)) {
+            // expand layer: fragment-ordered weights with the BN scale folded in, shift as three bf16 terms in the extra k-step
+            const int K = s.cin, N = s.cout, KS = K / 16;
+            std::vector<unsigned short> wp(hpe_stream_bf16_weight_frags(N, K) * 8, 0);
+            for (int n = 0; n < N; ++n) {
+                const int blk = n >> 5, r = n & 31;
+                for (int h = 0; h < 2; ++h)
+                    for (int st = 0; st < KS; ++st)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = (K / 2) * h + 8 * st + j;
+                            wp[((((size_t)blk * (KS + 1) + st) * 64) + 32 * h + r) * 8 + j] = f2bf(sc[n] * L.kernel[(size_t)k * N + n]);
+                        }
+                float rest = sh[n];
+                for (int j = 0; j < 3; ++j) {
+                    const unsigned short b = f2bf(rest);
+                    unsigned u = (unsigned)b << 16;
+                    float bf;
+                    memcpy(&bf, &u, 4);
+                    rest -= bf;
+                    wp[((((size_t)blk * (KS + 1) + KS) * 64) + r) * 8 + j] = b;
+                }
+            }
+            void* q = nullptr;
+            HIP_TRY(hipMalloc(&q, wp.size() * 2));
+            c->allocs.push_back(q);
+            HIP_TRY(hipMemcpy(q, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+            L.w_stream = q;
+        }
         std::vector<float>().swap(L.kernel);
     }
     // constants every part uses: the zero page is the LDS-DMA source of out-of-image taps / halo pixels

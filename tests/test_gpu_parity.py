@@ -337,6 +337,24 @@ def test_dual_source_gemm_equals_two_launches(assets, dtype):
         assert l2 < 3e-3
 
 
+def test_bf16_streaming_expand_equals_generic_kernel(assets):
+    """bf16 identity-block expand layers (res*_branch2c, K = 64 / 128 / 256) through conv1x1_stream_bf16.hip (default) against
+    the generic implicit-GEMM kernel (HPE_STREAM=0), on a batch whose 28x28 / 14x14 pixel counts are not multiples of the
+    32-pixel tile (B = 3: 2352 and 588 pixels -> masked tail tiles).  The streaming form folds the BN scale into the bf16
+    weights, so the two differ by one bf16 rounding of a weight; against the bf16-emulating oracle both sit at ~1e-3."""
+    img = gpu(synthetic.make_images(3, seed=80))
+    f = []
+    for env in ({"HPE_STREAM": "0"}, {}):
+        e = _engine_with_env(assets, env, 4, encoder_dtype="bf16")
+        f.append(cpu(e.encoder(img)).astype(np.float64))
+        e.close()
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    emu = O.resnet50_features(cpu(img), assets["enc"], act_round="bf16").astype(np.float64)
+    print("bf16 streaming expand: vs generic %.3g, vs emulating oracle %.3g (generic vs oracle %.3g)" % (l2(f[1], f[0]), l2(f[1], emu), l2(f[0], emu)))
+    assert l2(f[1], f[0]) < 3e-3
+    assert l2(f[1], emu) < 3e-3
+
+
 def test_pools(engine):
     import ctypes as C
 
