@@ -78,8 +78,14 @@ __device__ __forceinline__ void slab_advance_b(const GemmArgs& p, SlabB& sp) {
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dma_kernel(GemmArgs p) {
+// s_waitcnt vmcnt(n), n <= 63, everything else unconstrained (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
+#define HPE_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+
+// NS = LDS ring depth.  At the bf16 matrix rate one 64-deep slab is 0.25-0.5 us of MFMA work per wave, less than the latency of
+// the LDS-DMA that fetches the next one: with the plain double buffer (NS = 2) every slab waits for its DMA.  NS = 3 / 4 keeps
+// NS - 1 slabs in flight behind counted vmcnt waits (one barrier per slab as before).
+template <int MODE, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (WM * WN) / 4 : (WM * WN) / 2) void conv_gemm_bf16_dma_kernel(GemmArgs p) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
     constexpr int NW = WM * WN;
@@ -88,9 +94,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dm
     constexpr int BP = BN / (8 * NW);
     constexpr int EP = BN + 4;
     constexpr int BUF = (BM + BN) * RF;
-    constexpr int LDS_FLOATS = (2 * BUF > BM * EP) ? 2 * BUF : BM * EP;
+    constexpr int LDS_FLOATS = (NS * BUF > BM * EP) ? NS * BUF : BM * EP;
+    constexpr int NDMA = AP + BP;  // LDS-DMA instructions per wave and slab
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(AP >= 1 && BP >= 1, "tile too small for the wave count");
+    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * NDMA <= 63, "ring depth");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
@@ -186,14 +195,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dm
         }
     };
 
-    issue_dma(0, 0);
-    __syncthreads();
-
+    // ---- ring of NS slab buffers: slabs s+1 .. s+NS-1 are in flight while slab s is multiplied
+    {
+        const int npre = (NS - 1 < S) ? NS - 1 : S;
+        for (int i = 0; i < npre; ++i) {
+            if (i > 0) slab_advance_b<MODE>(p, sp);
+            issue_dma(i, i * BUF);
+        }
+    }
+    int cur = 0;               // buffer of slab s
+    int nxt = (NS - 1) * BUF;  // buffer of slab s + NS - 1 (== the buffer slab s - 1 just vacated)
     for (int s = 0; s < S; ++s) {
-        const int cur = (s & 1) * BUF;
-        if (s + 1 < S) {
+        // this wave's part of slab s has landed once at most min(NS-2, S-1-s) younger slabs are outstanding; the barrier extends
+        // that to every wave's part, and tells that every wave is done reading the buffer of slab s-1
+        const int ahead = (S - 1 - s < NS - 2) ? S - 1 - s : NS - 2;
+        if (ahead <= 0) HPE_WAIT_VMCNT(0);
+        else if (ahead == 1) HPE_WAIT_VMCNT(NDMA);
+        else HPE_WAIT_VMCNT(2 * NDMA);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < S) {
             slab_advance_b<MODE>(p, sp);
-            issue_dma(s + 1, BUF - cur);
+            issue_dma(s + NS - 1, nxt);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -208,8 +232,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dm
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        nxt = cur;
+        cur = (cur + BUF == NS * BUF) ? 0 : cur + BUF;
     }
+    __syncthreads();  // every wave is out of the last slab before the epilogue reuses the LDS
 
     // ---- epilogue: fp32 scale/shift, transpose through LDS, rows leave as 16 B (8 bf16) per lane
     {
@@ -271,24 +297,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_bf16_dm
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN, int NS>
 hipError_t launch_cfg_b(GemmArgs& p, hipStream_t st) {
     p.n_mtiles = (p.M + BM - 1) / BM;
     p.n_ntiles = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_gemm_bf16_dma_kernel<MODE, BM, BN, WM, WN>), dim3(p.n_mtiles * p.n_ntiles), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((conv_gemm_bf16_dma_kernel<MODE, BM, BN, WM, WN, NS>), dim3(p.n_mtiles * p.n_ntiles), dim3(64 * WM * WN), 0, st, p);
     return hipGetLastError();
 }
 
+// ring depth NS per tile: deeper rings only exist where they fit the 160 KB of LDS and were measured (profiles/r02)
+template <int MODE, int BM, int BN, int WM, int WN>
+hipError_t launch_ns(GemmArgs& p, int ns, hipStream_t st) {
+    constexpr int BUF_BYTES = (BM + BN) * 128;
+    if constexpr (4 * BUF_BYTES <= 160 * 1024) {
+        if (ns >= 4) return launch_cfg_b<MODE, BM, BN, WM, WN, 4>(p, st);
+    }
+    if constexpr (3 * BUF_BYTES <= 160 * 1024) {
+        if (ns >= 3) return launch_cfg_b<MODE, BM, BN, WM, WN, 3>(p, st);
+    }
+    return launch_cfg_b<MODE, BM, BN, WM, WN, 2>(p, st);
+}
+
 template <int MODE>
-hipError_t launch_mode_b(GemmArgs& p, int tile, hipStream_t st) {
+hipError_t launch_mode_b(GemmArgs& p, int tile, int ns, hipStream_t st) {
     switch (tile) {
-        case TILE_128x128: return launch_cfg_b<MODE, 128, 128, 2, 2>(p, st);
-        case TILE_128x64: return launch_cfg_b<MODE, 128, 64, 2, 2>(p, st);
-        case TILE_64x64: return launch_cfg_b<MODE, 64, 64, 2, 2>(p, st);
-        case TILE_64x128: return launch_cfg_b<MODE, 64, 128, 2, 2>(p, st);
-        case TILE_128x128_W8: return launch_cfg_b<MODE, 128, 128, 2, 4>(p, st);
-        case TILE_128x64_W8: return launch_cfg_b<MODE, 128, 64, 4, 2>(p, st);
-        case TILE_256x128_W8: return launch_cfg_b<MODE, 256, 128, 4, 2>(p, st);
+        case TILE_128x128: return launch_ns<MODE, 128, 128, 2, 2>(p, ns, st);
+        case TILE_128x64: return launch_cfg_b<MODE, 128, 64, 2, 2, 2>(p, st);
+        case TILE_64x64: return launch_cfg_b<MODE, 64, 64, 2, 2, 2>(p, st);
+        case TILE_64x128: return launch_ns<MODE, 64, 128, 2, 2>(p, ns, st);
+        case TILE_128x128_W8: return launch_ns<MODE, 128, 128, 2, 4>(p, ns, st);
+        case TILE_128x64_W8: return launch_ns<MODE, 128, 64, 4, 2>(p, ns, st);
+        case TILE_256x128_W8: return launch_ns<MODE, 256, 128, 4, 2>(p, ns, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -377,7 +416,7 @@ inline int grid_for(long total, int block, int cap = 2048) {
 
 }  // namespace
 
-hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st) {
+hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ns, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BKE) != 0 || (p.ldw % 8) != 0 || p.ldw < p.K) return hipErrorInvalidValue;
     if (!p.x || !p.w || !p.y || !p.scale || !p.shift || !p.zero) return hipErrorInvalidValue;
     if ((p.ldy % 8) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
@@ -388,24 +427,24 @@ hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st) 
     switch (mode) {
         case GEMM_DENSE:
             if (p.lda < p.K || (p.lda % 8) != 0) return hipErrorInvalidValue;
-            return launch_mode_b<GEMM_DENSE>(p, tile, st);
+            return launch_mode_b<GEMM_DENSE>(p, tile, ns, st);
         case GEMM_STRIDED:
             if (p.Cin != p.K || (p.Cin % 8) != 0) return hipErrorInvalidValue;
             if ((p.Ho - 1) * p.stride >= p.Hi || (p.Wo - 1) * p.stride >= p.Wi) return hipErrorInvalidValue;
-            return launch_mode_b<GEMM_STRIDED>(p, tile, st);
+            return launch_mode_b<GEMM_STRIDED>(p, tile, ns, st);
         case GEMM_CONV3:
             if ((p.Cin % BKE) != 0 || p.K != 9 * p.Cin || p.cin_slabs != p.Cin / BKE || p.Ho != p.Hi || p.Wo != p.Wi)
                 return hipErrorInvalidValue;
-            return launch_mode_b<GEMM_CONV3>(p, tile, st);
+            return launch_mode_b<GEMM_CONV3>(p, tile, ns, st);
         case GEMM_STEM:
             if (p.K != 4 * BKE || p.Hi < 2 * (p.Ho - 1) + 8 || p.Wi < 2 * (p.Wo - 1) + 8) return hipErrorInvalidValue;
-            return launch_mode_b<GEMM_STEM>(p, tile, st);
+            return launch_mode_b<GEMM_STEM>(p, tile, ns, st);
         case GEMM_DUAL:
             if (!p.x2 || ((uintptr_t)p.x2 & 15) != 0 || p.k1_slabs < 1 || p.k1_slabs * BKE >= p.K || p.lda < p.k1_slabs * BKE || (p.lda % 8) != 0)
                 return hipErrorInvalidValue;
             if (p.Cin != p.K - p.k1_slabs * BKE || (p.Cin % 8) != 0 || p.M != (p.M / (p.Ho * p.Wo)) * p.Ho * p.Wo) return hipErrorInvalidValue;
             if ((p.Ho - 1) * p.stride >= p.Hi || (p.Wo - 1) * p.stride >= p.Wi) return hipErrorInvalidValue;
-            return launch_mode_b<GEMM_DUAL>(p, tile, st);
+            return launch_mode_b<GEMM_DUAL>(p, tile, ns, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -91,7 +91,6 @@ struct ConvLayer {
     float* w_dual = nullptr;
     float* shift_dual = nullptr;
     int k_dual = 0, k1_dual = 0;
-    void* w_stream = nullptr; // bf16, *_branch2c of identity blocks: weights in the fragment order of conv1x1_stream_bf16.hip
     void* stem_w = nullptr;   // conv1 only: weights in the k enumeration of stem_fused.hip (fp32 [64][160] / bf16 [64][7][32])
     float* wino_u = nullptr;  // device, G g G^T in the blocked layout of conv_wino.hip (3x3 layers on the Winograd path only)
     int n_pad = 0, k_pad = 0;
@@ -122,6 +121,8 @@ constexpr size_t WINO_V_SLACK = 524288;
 // tile-selection overrides (HPE_TILE_WIDE / HPE_TILE_NARROW / HPE_SHORTK_TILE / HPE_TILE_BF16), read once in hpe_finalize
 struct TileKnobs {
     int force_wide = -1, force_narrow = -1, shortk = TILE_128x64_W8, force_bf16 = -1;
+    int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
+    int bf16_rules = 1;      // HPE_BF16_RULES=0: the round-1 tile rule (128x128 / 64x128 by grid size, double buffer)
 };
 
 struct hpe_ctx {
@@ -167,7 +168,6 @@ struct hpe_ctx {
     int wino_min_c = 128;     // 3x3 layers with at least this many channels take the Winograd path
     int wino_min_items = 128; // ... when the launch has at least this many workgroups
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
-    int stream_expand = 1;    // bf16: identity-block expand layers through the streaming kernel (HPE_STREAM=0: generic implicit GEMM)
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
@@ -227,11 +227,29 @@ int pick_tile(const TileKnobs& kn, int M, int N, int K) {
     return TILE_64x64;
 }
 
-int pick_tile_bf16(const TileKnobs& kn, int M, int N) {
-    if (N <= 64) return TILE_128x64;
-    if (kn.force_bf16 >= 0) return kn.force_bf16;
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    return t128 >= 512 ? TILE_128x128 : TILE_64x128;
+struct Bf16Plan {
+    int tile, ns;
+};
+
+// bf16 tile + ring depth per layer kind, from the per-layer sweeps in profiles/r02 (B = 256):
+//  * identity-block expand layers (1x1, K = C, N = 4C, + residual): all epilogue -> 128x64 with 8 waves issuing the row stores
+//    and residual loads (res2b_branch2c 0.273 -> 0.182 ms = 5.1 TB/s, res3* 0.157 -> 0.108, res4* 0.079 -> 0.062, res5* 0.061 -> 0.048)
+//  * everything with a long k axis on the small maps (stage 5: M = 49 B): 256x128, 8 waves (res5*_branch2b 0.112 -> 0.083 ms)
+//  * otherwise 128x128 while that still gives >= 512 workgroups, else 64x128
+Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expand) {
+    Bf16Plan pl{TILE_128x64, 2};
+    if (N > 64) {
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        pl.tile = t128 >= 512 ? TILE_128x128 : TILE_64x128;
+        if (kn.bf16_rules) {
+            if (residual_expand) pl.tile = TILE_128x64_W8;
+            else if (M <= 16384 && M >= 8192 && K >= 1024 && N >= 256) pl.tile = TILE_256x128_W8;
+        }
+        if (kn.force_bf16 >= 0) pl.tile = kn.force_bf16;
+    }
+    if (kn.bf16_rules && K >= 512) pl.ns = 3;  // >= 8 slabs: worth a deeper ring where the tile's LDS allows it
+    if (kn.force_ns_bf16 >= 2) pl.ns = kn.force_ns_bf16;
+    return pl;
 }
 
 #define HIPE(expr)                               \
@@ -317,9 +335,9 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         mode = GEMM_STRIDED;
     }
     if (c->bf16) {
-        if (L.w_stream && res) return hpe_launch_conv1x1_stream_bf16(x, L.w_stream, res, y, p.M, p.N, s.cin, relu, st);
         p.cin_slabs = s.cin / 64;
-        return hpe_launch_gemm_bf16(p, mode, pick_tile_bf16(c->knobs, p.M, p.N), st);
+        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin);
+        return hpe_launch_gemm_bf16(p, mode, pl.tile, pl.ns, st);
     }
     return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K), st);
 }
@@ -355,7 +373,10 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
         p.partial = c->partial;
         p.partial_floats = c->partial_floats;
     }
-    if (c->bf16) return hpe_launch_gemm_bf16(p, GEMM_DUAL, pick_tile_bf16(c->knobs, p.M, p.N), st);
+    if (c->bf16) {
+        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, false);
+        return hpe_launch_gemm_bf16(p, GEMM_DUAL, pl.tile, pl.ns, st);
+    }
     return hpe_launch_gemm(p, GEMM_DUAL, pick_tile(c->knobs, p.M, p.N, p.K), st);
 }
 
@@ -725,8 +746,10 @@ static int finalize_impl(hpe_ctx* c) {
         c->stem_fused = e ? atoi(e) : 1;
         e = getenv("HPE_DUAL");
         c->dual_gemm = e ? atoi(e) : 1;
-        e = getenv("HPE_STREAM");
-        c->stream_expand = e ? atoi(e) : 1;
+        e = getenv("HPE_NS_BF16");
+        c->knobs.force_ns_bf16 = e ? atoi(e) : -1;
+        e = getenv("HPE_BF16_RULES");
+        c->knobs.bf16_rules = e ? atoi(e) : 1;
         // per-device function attributes (dynamic LDS above 64 KB) of the Winograd and stem kernels
         HIP_TRY(hpe_wino_init_device());
         HIP_TRY(hpe_stem_fused_init_device());
@@ -862,34 +885,6 @@ static int finalize_impl(hpe_ctx* c) {
         }
         if ((rc = upload(c, &L.scale, sc))) return rc;
         if ((rc = upload(c, &L.shift, sh))) return rc;
-        if (c->bf16 && c->stream_expand && s.kh == 1 && s.stride == 1 && s.cout == 4 * s.cin && hpe_stream_bf16_supported(s.cout, s.cin)) {
-            // expand layer: fragment-ordered weights with the BN scale folded in, shift as three bf16 terms in the extra k-step
-            const int K = s.cin, N = s.cout, KS = K / 16;
-            std::vector<unsigned short> wp(hpe_stream_bf16_weight_frags(N, K) * 8, 0);
-            for (int n = 0; n < N; ++n) {
-                const int blk = n >> 5, r = n & 31;
-                for (int h = 0; h < 2; ++h)
-                    for (int st = 0; st < KS; ++st)
-                        for (int j = 0; j < 8; ++j) {
-                            const int k = (K / 2) * h + 8 * st + j;
-                            wp[((((size_t)blk * (KS + 1) + st) * 64) + 32 * h + r) * 8 + j] = f2bf(sc[n] * L.kernel[(size_t)k * N + n]);
-                        }
-                float rest = sh[n];
-                for (int j = 0; j < 3; ++j) {
-                    const unsigned short b = f2bf(rest);
-                    unsigned u = (unsigned)b << 16;
-                    float bf;
-                    memcpy(&bf, &u, 4);
-                    rest -= bf;
-                    wp[((((size_t)blk * (KS + 1) + KS) * 64) + r) * 8 + j] = b;
-                }
-            }
-            void* q = nullptr;
-            HIP_TRY(hipMalloc(&q, wp.size() * 2));
-            c->allocs.push_back(q);
-            HIP_TRY(hipMemcpy(q, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
-            L.w_stream = q;
-        }
         std::vector<float>().swap(L.kernel);
     }
     // constants every part uses: the zero page is the LDS-DMA source of out-of-image taps / halo pixels

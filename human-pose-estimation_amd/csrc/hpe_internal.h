@@ -58,7 +58,7 @@ int hpe_wino_fused_items(int B, int H, int W, int N);  // work items of that lau
 hipError_t hpe_launch_nhwc_to_slab8(const float* x, float* xs, long M, int C, hipStream_t st);
 
 // conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
-hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, hipStream_t st);
+hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ring_depth, hipStream_t st);  // ring_depth 2..4 LDS slab buffers
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
 hipError_t hpe_launch_maxpool_bf16(const void* x, void* y, int B, int H, int C, hipStream_t st);
 hipError_t hpe_launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, int ldy, hipStream_t st);
@@ -70,15 +70,6 @@ hipError_t hpe_launch_stem_fused(const float* img, const void* w, const float* s
                                  hipStream_t st);
 hipError_t hpe_stem_fused_init_device();
 int hpe_stem_fused_pick_rows(int B);
-
-// conv1x1_stream_bf16.hip: y[M][N] = act(x[M][K] . W'^T + shift + res) in bf16 for the short-K expand layers (K = 64 / 128 / 256),
-// streaming (no LDS); w_packed from hpe_stream_bf16_weight_frags(N, K) 16-B fragments laid out [N/32][K/16 + 1][64 lanes]:
-// lane (r = lane & 31, h = lane >> 5) of k-step s < K/16 holds scale[n] * W[n = 32 blk + r][k = (K/2) h + 8 s + j], j < 8;
-// k-step K/16 holds the three bf16 terms of shift[n] in j = 0..2 of the lower half, zeros elsewhere
-int hpe_stream_bf16_supported(int N, int K);
-size_t hpe_stream_bf16_weight_frags(int N, int K);
-hipError_t hpe_launch_conv1x1_stream_bf16(const void* x, const void* w_packed, const void* res, void* y, int M, int N, int K, int relu,
-                                          hipStream_t st);
 
 // encoder_ops.hip
 hipError_t hpe_launch_pad_input(const float* img, float* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);

@@ -249,7 +249,7 @@ def _t(x, dtype):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
 
 
-def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False, act_round=None):
+def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False, act_round=None, bf16_folded=()):
     """reference: src/models.py:35-41 -> keras.applications.ResNet50(include_top=False, pooling='avg')
     (keras_applications 1.0.8 resnet50.py; BN epsilon 1e-3 there, 1.001e-5 in tf.keras>=2.2 resnet.py --
     hence the parameter).  images [B,224,224,3] NHWC in [-1,1] -> features [B,2048].
@@ -265,13 +265,24 @@ def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False, 
     # act_round="bf16": emulation of the bf16 encoder variant (BASELINE config 4) -- the input, the conv kernels and
     # every stored activation (after BN / residual add / ReLU) are rounded to bfloat16 (RNE); accumulation, BN
     # scale/shift and the pools stay in `dtype`.  Not a reference behaviour: a checker for the bf16 HIP path.
+    # bf16_folded (emulation only): layer names whose HIP kernels fold the BN scale into the weights BEFORE rounding them to
+    # bfloat16 (the dual-source conv_block GEMM: "<block>2c" and "<block>1"; there the shortcut is also summed in the fp32
+    # accumulator instead of being stored as a bf16 tensor).  Mathematically the same layer, different rounding points.
     rnd = (lambda v: v.to(torch.bfloat16).to(tdt)) if act_round == "bf16" else (lambda v: v)
 
     def conv(x, name, stride=1, padding=0):
-        w = rnd(_t(p[name + "/kernel"], tdt)).permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
-        return F.conv2d(x, w, _t(p[name + "/bias"], tdt), stride=stride, padding=padding)
+        w = _t(p[name + "/kernel"], tdt)
+        if name in bf16_folded:
+            bnn = "bn" + name[3:]
+            w = w * (_t(p[bnn + "/gamma"], tdt) * torch.rsqrt(_t(p[bnn + "/moving_variance"], tdt) + eps))  # HWIO: scale the O axis
+        w = rnd(w).permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
+        return F.conv2d(x, w, None if name in bf16_folded else _t(p[name + "/bias"], tdt), stride=stride, padding=padding)
 
     def bn(x, name):
+        if "res" + name[2:] in bf16_folded:  # scale already in the weights: only the shift ((bias - mean) * scale + beta) is left
+            sc_ = _t(p[name + "/gamma"], tdt) * torch.rsqrt(_t(p[name + "/moving_variance"], tdt) + eps)
+            sh_ = (_t(p["res" + name[2:] + "/bias"], tdt) - _t(p[name + "/moving_mean"], tdt)) * sc_ + _t(p[name + "/beta"], tdt)
+            return x + sh_[None, :, None, None]
         g = _t(p[name + "/gamma"], tdt)[None, :, None, None]
         b = _t(p[name + "/beta"], tdt)[None, :, None, None]
         m = _t(p[name + "/moving_mean"], tdt)[None, :, None, None]
@@ -295,7 +306,12 @@ def resnet50_features(images, p, eps=1e-3, dtype=np.float32, return_taps=False, 
                 y = rnd(torch.relu(bn(conv(x, cn + "2a", stride=s), bnn + "2a")))
                 y = rnd(torch.relu(bn(conv(y, cn + "2b", padding=1), bnn + "2b")))
                 y = bn(conv(y, cn + "2c"), bnn + "2c")
-                sc = rnd(bn(conv(x, cn + "1", stride=s), bnn + "1")) if b == 0 else x
+                if b == 0:
+                    sc = bn(conv(x, cn + "1", stride=s), bnn + "1")
+                    if cn + "1" not in bf16_folded:
+                        sc = rnd(sc)  # stored as a bf16 tensor by the two-launch path; summed in fp32 by the dual-source GEMM
+                else:
+                    sc = x
                 x = rnd(torch.relu(y + sc))
                 taps["res%d%s" % (stage, blk)] = x
         feat = x.mean(dim=(2, 3))

@@ -20,9 +20,12 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
-def last_pass(rows, key="pad_input_kernel"):
-    """rows sorted by start; keep the dispatches from the last pad_input_kernel on (one forward = one pad launch per chunk)"""
-    idx = [i for i, r in enumerate(rows) if key in r[0]]
+FIRST_KERNELS = ("stem_fused_", "pad_input")  # the first launch of a forward pass (fused stem; pad pass with HPE_STEM_FUSED=0)
+
+
+def last_pass(rows):
+    """rows sorted by start; keep the dispatches from the last forward's first kernel on (HPE_STREAMS=1: one such launch per forward)"""
+    idx = [i for i, r in enumerate(rows) if any(k in r[0] for k in FIRST_KERNELS)]
     return rows[idx[-1]:] if idx else rows
 
 
@@ -43,8 +46,8 @@ def pmc_rows(db):
     if not need <= set(cols):
         raise SystemExit("unexpected columns %s" % cols)
     rows = list(cur.execute("select kernel_name, dispatch_id, counter_name, sum(value) from %s group by dispatch_id, counter_name order by dispatch_id" % view))
-    # split at the last pad_input_kernel dispatch
-    pads = [r[1] for r in rows if "pad_input_kernel" in r[0]]
+    # split at the last forward's first kernel
+    pads = [r[1] for r in rows if any(k in r[0] for k in FIRST_KERNELS)]
     first = max(pads) if pads else 0
     return [r for r in rows if r[1] >= first]
 
@@ -82,7 +85,7 @@ def main():
         tot_t += ms
         tot_b += fb + wb
     print("\ntotal %.2f ms, %.2f GB" % (tot_t, tot_b / 1e9))
-    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_")]
+    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream")]
     cf = sum(fetch.get(k, 0.0) for k in conv)
     cw = sum(write.get(k, 0.0) for k in conv)
     print("\nJSON " + json.dumps({"fetch_bytes_corrected": cf, "write_bytes": cw, "total_bytes": cf + cw, "kernels": sorted(conv)}))

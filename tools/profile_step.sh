@@ -1,12 +1,14 @@
 #!/bin/bash
 # rocprofv3 passes over one bench step (run on the GPU box from the repo root): kernel trace + separate PMC passes.
-# usage: bash tools/profile_step.sh <outdir under gpurun_out>
+# usage: bash tools/profile_step.sh <outdir under gpurun_out> [extra bench.py arguments, e.g. --encoder-dtype bf16 / --config5]
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
+shift
+EXTRA="$@"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export HPE_STREAMS=1
-B="$GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --no-roofline"
+B="$GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --no-roofline --sustain 0 $EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $B --steps 1 --warmup 1 > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $B --steps 1 --warmup 0 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $B --steps 1 --warmup 0 > $OUT/write.log 2>&1
