@@ -81,9 +81,11 @@ __device__ __forceinline__ void slab_advance_b(const GemmArgs& p, SlabB& sp) {
 // s_waitcnt vmcnt(n), n <= 63, everything else unconstrained (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
 #define HPE_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
-// NS = LDS ring depth.  At the bf16 matrix rate one 64-deep slab is 0.25-0.5 us of MFMA work per wave, less than the latency of
-// the LDS-DMA that fetches the next one: with the plain double buffer (NS = 2) every slab waits for its DMA.  NS = 3 / 4 keeps
-// NS - 1 slabs in flight behind counted vmcnt waits (one barrier per slab as before).
+// NS = LDS ring depth: NS - 1 slabs in flight behind counted vmcnt waits and a raw s_barrier (one barrier per slab).  NS = 2 is
+// the shipped configuration.  NS = 3 (HPE_NS_BF16=3, kept for the 128x128 and 256x128 tiles) was the experiment "is the slab DMA
+// latency exposed at the bf16 matrix rate?" -- it is not: the deeper ring halves the workgroups per CU (96 KB of LDS) and LOSES
+// 30-45 % on the 3x3 layers (res4*_branch2b 0.080 -> 0.117 ms; profiles/r02/bf16_ring_depth.txt): block-level overlap of two
+// workgroups per CU already hides the DMA, the kernel sits at the ceiling of the one-barrier-per-slab structure.
 template <int MODE, int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (WM * WN) / 4 : (WM * WN) / 2) void conv_gemm_bf16_dma_kernel(GemmArgs p) {
     constexpr int MT = BM / WM / 32;
@@ -203,37 +205,43 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (W
             issue_dma(i, i * BUF);
         }
     }
-    int cur = 0;               // buffer of slab s
-    int nxt = (NS - 1) * BUF;  // buffer of slab s + NS - 1 (== the buffer slab s - 1 just vacated)
-    for (int s = 0; s < S; ++s) {
-        // this wave's part of slab s has landed once at most min(NS-2, S-1-s) younger slabs are outstanding; the barrier extends
-        // that to every wave's part, and tells that every wave is done reading the buffer of slab s-1
-        const int ahead = (S - 1 - s < NS - 2) ? S - 1 - s : NS - 2;
-        if (ahead <= 0) HPE_WAIT_VMCNT(0);
-        else if (ahead == 1) HPE_WAIT_VMCNT(NDMA);
-        else HPE_WAIT_VMCNT(2 * NDMA);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + NS - 1 < S) {
-            slab_advance_b<MODE>(p, sp);
-            issue_dma(s + NS - 1, nxt);
+    // The ring position must be a compile-time constant in every copy of the loop body (u below, fully unrolled): with a
+    // run-time buffer offset hipcc can neither prove the 16-B alignment of the fragment reads (they decay to ds_read2_b32) nor that
+    // they do not alias the LDS-DMA it has just issued (it then waits vmcnt(0) in front of them, which serialises the DMA latency).
+    for (int s0 = 0; s0 < S; s0 += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int s = s0 + u;
+            if (s >= S) break;
+            const int cur = u * BUF;                    // buffer of slab s
+            const int nxt = ((u + NS - 1) % NS) * BUF;  // buffer of slab s + NS - 1 (== the one slab s - 1 has just vacated)
+            // this wave's part of slab s has landed once at most min(NS-2, S-1-s) younger slabs are outstanding; the barrier
+            // extends that to every wave's part, and tells that every wave is done reading the buffer of slab s-1
+            const int ahead = (S - 1 - s < NS - 2) ? S - 1 - s : NS - 2;
+            if (ahead <= 0) HPE_WAIT_VMCNT(0);
+            else if (ahead == 1) HPE_WAIT_VMCNT(NDMA);
+            else HPE_WAIT_VMCNT(2 * NDMA);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + NS - 1 < S) {
+                slab_advance_b<MODE>(p, sp);
+                issue_dma(s + NS - 1, nxt);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x8 fa[MT], fb[NT];
+                const int lc = 2 * g + hi;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + a_row[i] + ((lc ^ a_x[i]) << 2)]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&lds[cur + b_row[j] + ((lc ^ b_x[j]) << 2)]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x8 fa[MT], fb[NT];
-            const int lc = 2 * g + hi;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + a_row[i] + ((lc ^ a_x[i]) << 2)]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&lds[cur + b_row[j] + ((lc ^ b_x[j]) << 2)]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        nxt = cur;
-        cur = (cur + BUF == NS * BUF) ? 0 : cur + BUF;
     }
     __syncthreads();  // every wave is out of the last slab before the epilogue reuses the LDS
 
@@ -305,16 +313,10 @@ hipError_t launch_cfg_b(GemmArgs& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ring depth NS per tile: deeper rings only exist where they fit the 160 KB of LDS and were measured (profiles/r02)
+// ring depth: 2 everywhere; 3 only on request (HPE_NS_BF16=3) for the two tiles it was measured on
 template <int MODE, int BM, int BN, int WM, int WN>
 hipError_t launch_ns(GemmArgs& p, int ns, hipStream_t st) {
-    constexpr int BUF_BYTES = (BM + BN) * 128;
-    if constexpr (4 * BUF_BYTES <= 160 * 1024) {
-        if (ns >= 4) return launch_cfg_b<MODE, BM, BN, WM, WN, 4>(p, st);
-    }
-    if constexpr (3 * BUF_BYTES <= 160 * 1024) {
-        if (ns >= 3) return launch_cfg_b<MODE, BM, BN, WM, WN, 3>(p, st);
-    }
+    if (ns >= 3) return launch_cfg_b<MODE, BM, BN, WM, WN, 3>(p, st);
     return launch_cfg_b<MODE, BM, BN, WM, WN, 2>(p, st);
 }
 
@@ -324,9 +326,9 @@ hipError_t launch_mode_b(GemmArgs& p, int tile, int ns, hipStream_t st) {
         case TILE_128x128: return launch_ns<MODE, 128, 128, 2, 2>(p, ns, st);
         case TILE_128x64: return launch_cfg_b<MODE, 128, 64, 2, 2, 2>(p, st);
         case TILE_64x64: return launch_cfg_b<MODE, 64, 64, 2, 2, 2>(p, st);
-        case TILE_64x128: return launch_ns<MODE, 64, 128, 2, 2>(p, ns, st);
-        case TILE_128x128_W8: return launch_ns<MODE, 128, 128, 2, 4>(p, ns, st);
-        case TILE_128x64_W8: return launch_ns<MODE, 128, 64, 4, 2>(p, ns, st);
+        case TILE_64x128: return launch_cfg_b<MODE, 64, 128, 2, 2, 2>(p, st);
+        case TILE_128x128_W8: return launch_cfg_b<MODE, 128, 128, 2, 4, 2>(p, st);
+        case TILE_128x64_W8: return launch_cfg_b<MODE, 128, 64, 4, 2, 2>(p, st);
         case TILE_256x128_W8: return launch_ns<MODE, 256, 128, 4, 2>(p, ns, st);
         default: return hipErrorInvalidValue;
     }

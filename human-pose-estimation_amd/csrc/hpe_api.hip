@@ -247,8 +247,7 @@ Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expan
         }
         if (kn.force_bf16 >= 0) pl.tile = kn.force_bf16;
     }
-    if (kn.bf16_rules && K >= 512) pl.ns = 3;  // >= 8 slabs: worth a deeper ring where the tile's LDS allows it
-    if (kn.force_ns_bf16 >= 2) pl.ns = kn.force_ns_bf16;
+    if (kn.force_ns_bf16 >= 2) pl.ns = kn.force_ns_bf16;  // experiment knob: a 3-deep ring lost everywhere (conv_gemm_bf16.hip)
     return pl;
 }
 

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void smpl_skin_kernel(SmplDev d, const float* 
     float vp[IT][3];
 #pragma unroll
     for (int i = 0; i < IT; ++i) vp[i][0] = vp[i][1] = vp[i][2] = 0.f;
-#pragma unroll 3
+    // 6 basis rows per batch: 18 vertex-basis loads and 6 scalar loads (48 SGPRs of pose feature) in flight per wave -- with 3 the
+    // 72 FMAs of a batch did not cover the scalar-load latency (66-70 us per launch against 21 us of FMA issue time)
+#pragma unroll 6
     for (int k = 0; k < 207; ++k) {
         const float* pd = d.posedirs + (size_t)k * V3 + 3 * v;
         const float p0 = pd[0], p1 = pd[1], p2 = pd[2];
@@ -250,6 +252,8 @@ __global__ __launch_bounds__(256) void joint_regress_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
     const float* Xn = X + (size_t)n * V3;
+    // one workgroup per mesh = 4 waves per CU: nothing hides a load but the loads of the same thread -> 4 vertices (28 loads) in flight
+#pragma unroll 4
     for (int v = t; v < V; v += 256) {
         const float x0 = Xn[3 * v], x1 = Xn[3 * v + 1], x2 = Xn[3 * v + 2];
         const f32x4* rp = reinterpret_cast<const f32x4*>(reg + (size_t)v * 24);
