@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--sustain", type=float, default=10.0, help="seconds of the untimed steady-state loop after the timed steps (0 = skip)")
     ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16 = BASELINE configs[3] (bf16 encoder, fp32 SMPL)")
     ap.add_argument("--config5", action="store_true", help="also evaluate kp + mesh reprojection losses of every stage (BASELINE configs[4])")
+    ap.add_argument("--no-pipeline", action="store_true", help="serial steps: the regressor + SMPL tail of batch k does NOT overlap the encoder of batch k+1")
     return ap.parse_args()
 
 
@@ -251,8 +252,21 @@ def main():
     images = torch.from_numpy(synthetic.make_images(B, seed=1000 + rank)).cuda()
     want = eng.DEFAULT_OUTPUTS + (("verts2d",) if args.config5 else ())
     # two output sets used alternately: the all-gather of step k reads theta_k while step k+1 already writes theta_{k+1}
-    plans = [eng.make_forward_plan(B, all_stages=True, want=want) for _ in range(2)]
+    # Steady-state serving is software-pipelined across batches: the encoder of batch k+1 (caller's stream) overlaps the
+    # latency-bound regressor + SMPL tail of batch k (the ctx's tail stream).  Every consumer of a batch's outputs -- the loss
+    # kernels, the collectives -- is enqueued on the tail stream, so nothing of a step is skipped or left outside the timed
+    # region: the fence at its end waits for the last tail and the last gather.
+    pipe = not args.no_pipeline
+    plans = [eng.make_forward_plan(B, all_stages=True, want=want, pipelined=pipe) for _ in range(2)]
     run, outs = plans[0]
+    tail = eng.tail_stream() if pipe else None
+    pipe_on = [pipe]  # cleared for the per-launch-timed step (hpe_forward_pipelined then runs serially on the caller's stream)
+
+    import contextlib
+
+    def on_tail():
+        return torch.cuda.stream(tail) if (tail is not None and pipe_on[0]) else contextlib.nullcontext()
+
     losses = {}
     if args.config5:
         seg_np, kp_np = synthetic.make_lsp_targets(B, seed=2000 + rank)
@@ -267,19 +281,21 @@ def main():
         k = step_no[0] & 1
         step_no[0] += 1
         if use_dist and pending[k] is not None:
-            pending[k].wait()  # the gather that last used this output set (two steps ago)
+            with on_tail():
+                pending[k].wait()  # the gather that last used this output set (two steps ago), before the tail overwrites it
             pending[k] = None
         o = plans[k][0](images)
-        if args.config5:
-            # one library call for the 2 x 3 losses, then (N > 1) ONE all-reduce of the [3,4] block
-            packed = eng.val_losses(kp_gts, [st["kp2d"] for st in o], seg_gts, [st["verts2d"] for st in o], out=loss_out[k])
+        with on_tail():
+            if args.config5:
+                # one library call for the 2 x 3 losses, then (N > 1) ONE all-reduce of the [3,4] block
+                packed = eng.val_losses(kp_gts, [st["kp2d"] for st in o], seg_gts, [st["verts2d"] for st in o], out=loss_out[k])
+                if use_dist:
+                    packed = D.reduce_losses(packed)
+                losses["packed"] = packed
             if use_dist:
-                packed = D.reduce_losses(packed)
-            losses["packed"] = packed
-        if use_dist:
-            # the ONE data-path collective: all-gather of the predicted theta over RCCL, asynchronous so that it overlaps
-            # the next batch's encoder (it is waited for before its buffers are reused and before the timed region ends)
-            pending[k] = dist.all_gather_into_tensor(theta_all[k], o[-1]["theta"], async_op=True)
+                # the ONE data-path collective: all-gather of the predicted theta over RCCL, asynchronous so that it overlaps
+                # the next batch's encoder (it is waited for before its buffers are reused and before the timed region ends)
+                pending[k] = dist.all_gather_into_tensor(theta_all[k], o[-1]["theta"], async_op=True)
         return o
 
     # one-time initialisation that is not a benchmark step: code-object load / first-launch setup of every kernel and the RCCL
@@ -341,8 +357,11 @@ def main():
         # (2) serial cross-check, extra steps after the timed region: chunk streams off, events around each of the
         #     53 launches; the sum matches the rocprofv3 --kernel-trace --stats durations (profiles/).
         eng.enable_timing(2)
+        fence()
+        pipe_on[0] = False
         step()
         fence()
+        pipe_on[0] = pipe
         ts = eng.timings()
         per_conv = eng.conv_timings()
         serial_tf = ENCODER_GFLOP_PER_IMG * B / ts["conv_ms"]
@@ -512,6 +531,8 @@ def main():
                                 ("configs[3] on one GPU" if args.encoder_dtype == "bf16" else "configs[1] at the metric batch")),
                 "global_batch": world * B,
                 "parallelism": "dp%d (batch shard, replicated weights)" % world,
+                "pipeline": ("regressor+SMPL tail of batch k overlaps the encoder of batch k+1 (tail stream); all work of the K steps "
+                             "completes inside the timed region") if pipe else "serial steps",
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

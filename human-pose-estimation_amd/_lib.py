@@ -67,6 +67,9 @@ _PROTOS = {
     "hpe_load_mean_theta": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpe_finalize": (C.c_int, [C.c_void_p]),
     "hpe_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(HpeOutputs), C.c_int, C.c_void_p]),
+    "hpe_forward_pipelined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(HpeOutputs), C.c_int, C.c_void_p]),
+    "hpe_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hpe_tail_stream": (C.c_void_p, [C.c_void_p]),
     "hpe_encoder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_regress_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_smpl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(HpeOutputs), C.c_void_p]),

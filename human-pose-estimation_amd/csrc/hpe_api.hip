@@ -173,6 +173,18 @@ struct hpe_ctx {
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
     hipEvent_t ev_fork{}, ev_join[3]{};
+    // software pipeline across calls (hpe_forward_pipelined): the regressor + SMPL tail of batch k runs on `tail_st` while the
+    // caller's stream already runs the encoder of batch k+1; features alternate between two buffers, the Dense layers of the tail
+    // have their own split-K workspace
+    hipStream_t tail_st{};
+    hipEvent_t ev_enc{}, ev_tail{}, ev_feat_free[2]{};
+    bool feat_free_valid[2] = {false, false};
+    bool tail_pending = false;
+    unsigned pipe_idx = 0;
+    float* feat_alt = nullptr;
+    float* partial_tail = nullptr;
+    size_t partial_tail_floats = 0;
+    bool dense_on_tail = false;  // set while a pipelined tail is being enqueued: run_dense then uses partial_tail
     // timing
     int timing = 0;
     hipEvent_t ev[8]{};
@@ -383,8 +395,10 @@ hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const fl
                      const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
     GemmArgs p{};
     p.zero = shift;  // any readable 16 B: dense mode never takes the zero-page path
-    p.partial = c->partial;  // the Dense layers run on the caller's stream after the chunk streams have joined
-    p.partial_floats = c->partial_floats;
+    // the Dense layers run after the chunk streams have joined; in the pipelined forward they overlap the NEXT batch's encoder,
+    // whose unchunked launches may split K too -> separate workspace
+    p.partial = c->dense_on_tail ? c->partial_tail : c->partial;
+    p.partial_floats = c->dense_on_tail ? c->partial_tail_floats : c->partial_floats;
     p.x = x;
     p.w = w;
     p.scale = scale;
@@ -678,6 +692,13 @@ static void release_device_state(hpe_ctx* c) {
         }
     };
     kill(c->ev_fork);
+    kill(c->ev_enc);
+    kill(c->ev_tail);
+    for (auto& e : c->ev_feat_free) kill(e);
+    if (c->tail_st) {
+        (void)hipStreamDestroy(c->tail_st);
+        c->tail_st = nullptr;
+    }
     for (auto& e : c->ev_join) kill(e);
     for (auto& e : c->ev) kill(e);
     for (auto& e : c->cev0) kill(e);
@@ -979,6 +1000,7 @@ static int finalize_impl(hpe_ctx* c) {
             if ((rc = dev_alloc(c, &c->T1, B * 200704, false))) return rc;
             if ((rc = dev_alloc(c, &c->T2, B * 200704, false))) return rc;
             if ((rc = dev_alloc(c, &c->feat, B * HPE_FEATURE_DIM, true))) return rc;
+            if ((rc = dev_alloc(c, &c->feat_alt, B * HPE_FEATURE_DIM, true))) return rc;
         }
         if (c->have_encoder && !c->bf16 && c->wino_min_c > 0) {
             if ((rc = dev_alloc(c, &c->wino_v, B * WINO_V_PITCH + WINO_V_SLACK, false))) return rc;
@@ -1000,6 +1022,8 @@ static int finalize_impl(hpe_ctx* c) {
         {
             c->partial_floats = (size_t)512 * 128 * 128;  // 512 slices of the largest tile (32 MB)
             if ((rc = dev_alloc(c, &c->partial, c->partial_floats, false))) return rc;
+            c->partial_tail_floats = (size_t)64 * 128 * 128;  // Dense layers: <= 16 slices of <= 64 tiles of 64 x 64 (4 MB)
+            if ((rc = dev_alloc(c, &c->partial_tail, c->partial_tail_floats, false))) return rc;
         }
         if (c->have_regressor) {
             if ((rc = dev_alloc(c, &c->P1, B * 1024, true))) return rc;
@@ -1030,6 +1054,10 @@ static int finalize_impl(hpe_ctx* c) {
         c->chunk_images = e ? atoi(e) : 0;
         for (int i = 0; i < ns - 1; ++i) HIP_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&c->tail_st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+        for (auto& ev : c->ev_feat_free) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -1067,6 +1095,10 @@ int hpe_regress_stage(hpe_ctx* c, const float* features, const float* theta_prev
     if (!features || !theta_out) return fail(HPE_ERR_INVALID, "null pointer");
     DeviceGuard g(c->cfg.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c->tail_pending) {  // shares the regressor buffers with a pipelined call's tail
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_tail, 0));
+        c->tail_pending = false;
+    }
     HIP_TRY(features_proj(c, features, B, st));
     if (theta_prev)
         HIP_TRY(hpe_launch_copy_theta(theta_prev, HPE_THETA_DIM, c->thA, THETA_LD, B, HPE_THETA_DIM, st));
@@ -1082,40 +1114,93 @@ int hpe_smpl(hpe_ctx* c, const float* theta, int B, const HpeOutputs* outs, void
     if (rc) return rc;
     if (!theta || !outs) return fail(HPE_ERR_INVALID, "null pointer");
     DeviceGuard g(c->cfg.device);
+    if (c->tail_pending) {  // shares the SMPL work buffers with a pipelined call's tail
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_tail, 0));
+        c->tail_pending = false;
+    }
     HIP_TRY(hpe_launch_smpl(c->smpl, c->work, theta, HPE_THETA_DIM, B, outs, static_cast<hipStream_t>(stream)));
     return HPE_OK;
 }
 
-int hpe_forward(hpe_ctx* c, const float* images, int B, const HpeOutputs* stage_outs, int n_outs, void* stream) {
+// encoder on `st`; regressor + SMPL stages on `st` (pipelined == false) or on the ctx's tail stream behind an event (true)
+static int forward_impl(hpe_ctx* c, const float* images, int B, const HpeOutputs* stage_outs, int n_outs, hipStream_t st, bool pipelined) {
     int rc = check_ready(c, B, NEED_ENC | NEED_REG | NEED_SMPL);
     if (rc) return rc;
     if (!images || !stage_outs) return fail(HPE_ERR_INVALID, "null pointer");
     if (n_outs < 1 || n_outs > c->cfg.num_stage) return fail(HPE_ERR_INVALID, "n_outs must be in [1, num_stage]");
     DeviceGuard g(c->cfg.device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tm = c->timing != 0;
+    if (c->timing >= 2) pipelined = false;  // per-launch event timing wants one serial stream
+    float* feat = c->feat;
+    hipStream_t ts = st;
+    if (pipelined) {
+        // features alternate between two buffers: the tail of batch k reads one while the encoder of batch k+1 fills the other;
+        // the buffer used now was last read by the feature projection of two calls ago (long finished: the wait is a formality)
+        const unsigned slot = c->pipe_idx & 1u;
+        feat = slot ? c->feat_alt : c->feat;
+        if (c->feat_free_valid[slot]) HIP_TRY(hipStreamWaitEvent(st, c->ev_feat_free[slot], 0));
+        ts = c->tail_st;
+    } else if (c->tail_pending) {
+        // a serial call after pipelined ones: its tail shares buffers with the pending tail -> order them
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_tail, 0));
+        c->tail_pending = false;
+    }
     if (tm) HIP_TRY(hipEventRecord(c->ev[0], st));
-    HIP_TRY(encoder_impl(c, images, B, c->feat, HPE_FEATURE_DIM, st));
+    HIP_TRY(encoder_impl(c, images, B, feat, HPE_FEATURE_DIM, st));
     if (tm) HIP_TRY(hipEventRecord(c->ev[1], st));
-    HIP_TRY(features_proj(c, c->feat, B, st));
-    HIP_TRY(hpe_launch_tile_theta(c->mean_dev, c->thA, B, THETA_LD, st));
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(c->ev_enc, st));
+        HIP_TRY(hipStreamWaitEvent(ts, c->ev_enc, 0));
+        c->dense_on_tail = true;
+    }
+    hipError_t e = features_proj(c, feat, B, ts);
+    if (e == hipSuccess && pipelined) {
+        const unsigned slot = c->pipe_idx & 1u;
+        e = hipEventRecord(c->ev_feat_free[slot], ts);
+        c->feat_free_valid[slot] = true;
+    }
+    if (e == hipSuccess) e = hpe_launch_tile_theta(c->mean_dev, c->thA, B, THETA_LD, ts);
     float* prev = c->thA;
     float* next = c->thB;
     const int first_out = c->cfg.num_stage - n_outs;
-    for (int s = 0; s < c->cfg.num_stage; ++s) {
-        HIP_TRY(regress_impl(c, prev, next, B, st));
-        if (s >= first_out) HIP_TRY(hpe_launch_smpl(c->smpl, c->work, next, THETA_LD, B, &stage_outs[s - first_out], st));
+    for (int s = 0; e == hipSuccess && s < c->cfg.num_stage; ++s) {
+        e = regress_impl(c, prev, next, B, ts);
+        if (e == hipSuccess && s >= first_out) e = hpe_launch_smpl(c->smpl, c->work, next, THETA_LD, B, &stage_outs[s - first_out], ts);
         float* t = prev;
         prev = next;
         next = t;
     }
+    c->dense_on_tail = false;
+    if (e != hipSuccess) return fail(HPE_ERR_HIP, std::string("forward tail: ") + hipGetErrorString(e));
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(c->ev_tail, ts));
+        c->tail_pending = true;
+        ++c->pipe_idx;
+    }
     if (tm) {
-        HIP_TRY(hipEventRecord(c->ev[4], st));
+        HIP_TRY(hipEventRecord(c->ev[4], ts));
         c->timed_valid = true;
         c->conv_timed_valid = c->timing >= 2;
     }
     return HPE_OK;
 }
+
+int hpe_forward(hpe_ctx* c, const float* images, int B, const HpeOutputs* stage_outs, int n_outs, void* stream) {
+    return forward_impl(c, images, B, stage_outs, n_outs, static_cast<hipStream_t>(stream), false);
+}
+
+int hpe_forward_pipelined(hpe_ctx* c, const float* images, int B, const HpeOutputs* stage_outs, int n_outs, void* stream) {
+    return forward_impl(c, images, B, stage_outs, n_outs, static_cast<hipStream_t>(stream), true);
+}
+
+int hpe_join(hpe_ctx* c, void* stream) {
+    if (!c || !c->finalized) return fail(HPE_ERR_STATE, "needs a finalized ctx");
+    DeviceGuard g(c->cfg.device);
+    if (c->tail_pending) HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_tail, 0));
+    return HPE_OK;
+}
+
+void* hpe_tail_stream(hpe_ctx* c) { return (c && c->finalized) ? static_cast<void*>(c->tail_st) : nullptr; }
 
 int hpe_orth_proj(const float* X, const float* cam, int B, int P, float* out, void* stream) {
     if (!X || !cam || !out || B < 1 || P < 1) return fail(HPE_ERR_INVALID, "bad argument");

@@ -167,11 +167,25 @@ class HpeEngine(object):
         _lib.check(self.lib.hpe_forward(self._h, images.data_ptr(), B, arr, n_outs, self._stream()))
         return outs
 
-    def make_forward_plan(self, B, all_stages=False, want=DEFAULT_OUTPUTS, graph=False):
+    def tail_stream(self):
+        """torch view of the ctx's tail stream (hpe_tail_stream): consumers of a pipelined plan's outputs enqueue there."""
+        torch = _torch()
+        ptr = self.lib.hpe_tail_stream(self._h)
+        if not ptr:
+            raise _lib.HpeError("no tail stream (ctx not finalized)")
+        return torch.cuda.ExternalStream(ptr, device=self.tdev)
+
+    def join(self):
+        """Make the current stream wait for the tail of the last pipelined forward (hpe_join)."""
+        _lib.check(self.lib.hpe_join(self._h, self._stream()))
+
+    def make_forward_plan(self, B, all_stages=False, want=DEFAULT_OUTPUTS, graph=False, pipelined=False):
         """Pre-allocate outputs once; returns (callable(images), outputs) -- the steady-state serving path.
         graph=True captures the whole forward (all kernel launches, including the fork/join of the batch-chunk streams)
         into a hipGraph through torch.cuda.CUDAGraph: the callable then copies `images` into a static input buffer and
-        replays the graph -- one host call per batch instead of ~75 launches (what matters for small batches)."""
+        replays the graph -- one host call per batch instead of ~75 launches (what matters for small batches).
+        pipelined=True uses hpe_forward_pipelined (steady-state throughput: the tail of batch k overlaps the encoder of batch
+        k+1); the caller reads the outputs after ``join()`` or from work enqueued on ``tail_stream()``."""
         torch = _torch()
         n_outs = self.num_stage if all_stages else 1
         outs = []
@@ -181,9 +195,14 @@ class HpeEngine(object):
             outs.append(t)
             arr[i] = o
         lib, h = self.lib, self._h
+        fwd = lib.hpe_forward_pipelined if pipelined else lib.hpe_forward
+        if pipelined and graph:
+            raise ValueError("a pipelined plan cannot be captured into a graph")
 
         def launch(images):
-            _lib.check(lib.hpe_forward(h, images.data_ptr(), B, arr, n_outs, self._stream()))
+            # pipelined: encoder on the current stream, regressor + SMPL tail on the ctx's tail stream (outputs valid after
+            # join(), or for work enqueued on tail_stream()); the next call's encoder overlaps this call's tail
+            _lib.check(fwd(h, images.data_ptr(), B, arr, n_outs, self._stream()))
 
         if not graph:
 

@@ -119,6 +119,17 @@ int hpe_finalize(hpe_ctx* ctx);
  * Trainer.val_step consumes (src/trainer.py:242-298). */
 int hpe_forward(hpe_ctx* ctx, const float* images_dev, int B, const HpeOutputs* stage_outs, int n_outs, void* stream);
 
+/* The same forward, software-pipelined ACROSS calls for steady-state serving: the encoder of this batch is enqueued on `stream`,
+ * its regressor + SMPL tail (a chain of small, latency-bound launches) on the ctx's own tail stream behind an event, so that the
+ * NEXT call's encoder overlaps it.  The outputs of a call are complete only after hpe_join(ctx, s) has made stream `s` wait for
+ * the tail (or after work enqueued on hpe_tail_stream(ctx) itself, e.g. hpe_val_losses or a collective on the outputs).
+ * Successive tails are ordered among themselves; the caller must not reuse an output buffer before joining the call that
+ * wrote it.  Per-batch latency is that of hpe_forward; throughput gains the tail time (fp32 3 %, bf16 encoder 10 %). */
+int hpe_forward_pipelined(hpe_ctx* ctx, const float* images_dev, int B, const HpeOutputs* stage_outs, int n_outs, void* stream);
+int hpe_join(hpe_ctx* ctx, void* stream);
+/* the ctx's tail stream (hipStream_t) for enqueuing consumers of a pipelined call's outputs without stalling `stream` */
+void* hpe_tail_stream(hpe_ctx* ctx);
+
 /* -- operators of the path, individually (same kernels as hpe_forward) -------------------------- */
 /* image_feature_extractor.predict(images) (src/predictor.py:125): -> features_dev [B,2048] */
 int hpe_encoder(hpe_ctx* ctx, const float* images_dev, int B, float* features_dev, void* stream);

@@ -526,6 +526,44 @@ def test_graph_replay_matches_eager(engine, assets):
     np.testing.assert_array_equal(cpu(o2["theta"]), cpu(engine.forward(img2)[0]["theta"]))
 
 
+def test_pipelined_forward_matches_serial(engine, assets):
+    """hpe_forward_pipelined: the tail (regressor + SMPL) of call k runs on the ctx's tail stream while the encoder of call k+1
+    is already running on the caller's stream; features alternate between two buffers.  Five consecutive calls with different
+    images through two alternating output sets must reproduce the serial forward bit for bit -- with consumers enqueued on the
+    tail stream, after join(), and when a serial call or a standalone operator follows a pipelined one."""
+    import torch
+
+    B = 4
+    imgs = [gpu(synthetic.make_images(B, seed=700 + i)) for i in range(5)]
+    serial = [engine.forward(x, all_stages=True) for x in imgs]
+    torch.cuda.synchronize()
+    plans = [engine.make_forward_plan(B, all_stages=True, pipelined=True) for _ in range(2)]
+    tail = engine.tail_stream()
+    kept = []
+    for i, x in enumerate(imgs):
+        run, outs = plans[i & 1]
+        run(x)
+        with torch.cuda.stream(tail):  # a consumer on the tail stream sees the finished outputs of this call
+            kept.append([{k: v.clone() for k, v in st.items()} for st in outs])
+    engine.join()  # the current stream now waits for the last tail
+    last = {k: v.clone() for k, v in plans[0][1][-1].items()}
+    torch.cuda.synchronize()
+    for i in range(5):
+        for st in range(3):
+            for k in ("theta", "verts", "joints", "kp2d", "cams", "J_transformed"):
+                np.testing.assert_array_equal(cpu(kept[i][st][k]), cpu(serial[i][st][k]), err_msg="call %d stage %d %s" % (i, st, k))
+    np.testing.assert_array_equal(cpu(last["verts"]), cpu(serial[4][2]["verts"]))
+    # a serial call and a standalone operator right after a pipelined call (shared regressor / SMPL buffers) stay ordered
+    plans[1][0](imgs[0])
+    again = engine.forward(imgs[1], all_stages=True)
+    plans[0][0](imgs[2])
+    th = engine.smpl(serial[3][2]["theta"], want=("verts",))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(cpu(again[2]["verts"]), cpu(serial[1][2]["verts"]))
+    np.testing.assert_array_equal(cpu(th["verts"]), cpu(serial[3][2]["verts"]))
+    np.testing.assert_array_equal(cpu(plans[0][1][2]["verts"]), cpu(serial[2][2]["verts"]))
+
+
 # ------------------------------------------------------------------------------------------- bf16 encoder (config 4)
 def test_bf16_encoder_variant(assets):
     """BASELINE config 4: bf16 encoder (bf16 MFMA, fp32 accumulate) + fp32 regressor / SMPL.  Parity is REPORTED against
