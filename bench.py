@@ -200,9 +200,9 @@ def main():
     if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
         launch_ranks(args.gpus)  # does not return
 
-    # The encoder runs its batch chunks on 3 HIP streams and RCCL adds streams of its own; the HIP runtime multiplexes all
-    # streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and once two chunk streams share a queue
-    # their overlap is lost (measured: 20.1 -> 18.4 ms/step with a process group alive).  Must be set before HIP initialises.
+    # The encoder runs its batch chunks on 2 HIP streams, the regressor + SMPL tail on a third and RCCL adds its own; the HIP runtime
+    # multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and once two busy streams share a
+    # queue their overlap is lost (round 1: 20.1 -> 18.4 ms/step with a process group alive).  Must be set before HIP initialises.
     try:
         if int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) < 8:
             os.environ["GPU_MAX_HW_QUEUES"] = "8"
@@ -368,7 +368,7 @@ def main():
         PEAK = PEAK_FP32_MFMA_TFLOPS if args.encoder_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
         roofline = {
             "bound": "mfma",
-            "kernel": eng.encoder_kernel_description() + "; batch chunks on %s concurrent streams" % os.environ.get("HPE_STREAMS", "3"),
+            "kernel": eng.encoder_kernel_description() + "; batch chunks on %s concurrent streams" % os.environ.get("HPE_STREAMS", "2"),
             "achieved": round(achieved, 3),
             "peak": PEAK,
             "unit": "TFLOP/s",

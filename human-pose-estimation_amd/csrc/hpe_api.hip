@@ -1045,8 +1045,12 @@ static int finalize_impl(hpe_ctx* c) {
         c->work.Bpad = (int)Bpad;
     }
     {
+        // Two chunk streams by default: with the tail stream of the pipelined forward that makes 3 busy queues per process, and a
+        // 4th for RCCL.  A 5th concurrently busy queue is expensive on this part whatever GPU_MAX_HW_QUEUES says -- with a process
+        // group alive 3 chunk streams cost 6 % in fp32 and 24 % in bf16 (profiles/r02/streams_vs_rccl.txt) -- while 2 and 3 chunk
+        // streams are equal without one (17,306 vs 17,337 img/s).
         const char* e = getenv("HPE_STREAMS");
-        int ns = e ? atoi(e) : 3;
+        int ns = e ? atoi(e) : 2;
         if (ns < 1) ns = 1;
         if (ns > 4) ns = 4;
         c->n_streams = ns;
