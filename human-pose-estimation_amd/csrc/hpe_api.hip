@@ -121,6 +121,7 @@ constexpr size_t WINO_V_SLACK = 524288;
 // tile-selection overrides (HPE_TILE_WIDE / HPE_TILE_NARROW / HPE_SHORTK_TILE / HPE_TILE_BF16), read once in hpe_finalize
 struct TileKnobs {
     int force_wide = -1, force_narrow = -1, shortk = TILE_128x64_W8, force_bf16 = -1;
+    int force_expand = -1;   // HPE_EXPAND_TILE: fp32 tile of the identity-block expand layers (experiment knob)
     int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
     int bf16_rules = 1;      // HPE_BF16_RULES=0: the round-1 tile rule (128x128 / 64x128 by grid size, double buffer)
 };
@@ -223,17 +224,19 @@ int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
     return HPE_OK;
 }
 
-int pick_tile(const TileKnobs& kn, int M, int N, int K) {
+int pick_tile(const TileKnobs& kn, int M, int N, int K, bool residual_expand = false) {
     // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
     const bool wide = N > 64;
+    if (wide && residual_expand) return kn.force_expand >= 0 ? kn.force_expand : TILE_128x64_W8;
     if (wide && kn.force_wide >= 0) return kn.force_wide;
     if (!wide && kn.force_narrow >= 0) return kn.force_narrow;
     // Measured on MI355X (profiles/r01/d_tile_sweep.txt): with LDS-DMA staging the small tiles with 3-5 workgroups
     // per CU beat 128x128 at 2 per CU except on the huge-M layers of stages 2-3.
     if (!wide) return TILE_128x64;
-    // K <= 128 on the huge-M maps (the C -> 4C expand / projection layers of stages 2 and 3): two to four k-slabs only, the
-    // launch is all epilogue and HBM bound -> 8 waves to issue the row stores and residual loads win; 128x64 beats 128x128
-    // (profiles/r01/h_tile_128x64w8.txt: res2*_branch2c 0.41-0.43 -> 0.37-0.38 ms, res3*_branch2c 0.31 -> 0.28 ms)
+    // Identity-block expand layers (above) and K <= 128 on the huge-M maps (the C -> 4C expand / projection layers of stages 2 and
+    // 3): the launch is mostly epilogue -> 8 waves to issue the row stores and residual loads win; 128x64 beats 128x128
+    // (profiles/r01/h_tile_128x64w8.txt: res2*_branch2c 0.41-0.43 -> 0.37-0.38 ms, res3*_branch2c 0.31 -> 0.28 ms; stages 4-5:
+    // equal to the 64x64 tile within 1 %, profiles/r02/fp32_expand_tile.txt)
     if (K <= 128 && M >= 150000) return kn.shortk;
     if (M >= 150000) return TILE_64x128;
     return TILE_64x64;
@@ -350,7 +353,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin);
         return hpe_launch_gemm_bf16(p, mode, pl.tile, pl.ns, st);
     }
-    return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K), st);
+    return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin), st);
 }
 
 // branch2c (+BN) + branch1 (+BN) + add + ReLU of a conv_block as one dual-source GEMM: t2 [M, K1] dense, x NHWC strided
@@ -766,6 +769,8 @@ static int finalize_impl(hpe_ctx* c) {
         c->stem_fused = e ? atoi(e) : 1;
         e = getenv("HPE_DUAL");
         c->dual_gemm = e ? atoi(e) : 1;
+        e = getenv("HPE_EXPAND_TILE");
+        c->knobs.force_expand = e ? atoi(e) : -1;
         e = getenv("HPE_NS_BF16");
         c->knobs.force_ns_bf16 = e ? atoi(e) : -1;
         e = getenv("HPE_BF16_RULES");
