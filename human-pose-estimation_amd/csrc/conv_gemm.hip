@@ -752,31 +752,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_fixup_kernel(GemmArgs 
     conv_epilogue<BM, BN, WM, WN>(p, lds, acc, mtile * BM, ntile * BN, t, lane, wm, wn);
 }
 
+// environment knobs of the launcher: read once, in a thread-safe function-local static initialiser
 int stage_variant() {
-    static int v = -1;
-    if (v < 0) {
+    static const int v = [] {
         const char* e = getenv("HPE_STAGE");
-        v = (e && e[0] == 'r') ? 0 : 1;  // "reg" = register staged, default = LDS-DMA
-    }
+        return (e && e[0] == 'r') ? 0 : 1;  // "reg" = register staged, default = LDS-DMA
+    }();
     return v;
 }
 
 int sched_variant() {
-    static int v = -1;
-    if (v < 0) {
+    static const int v = [] {
         const char* e = getenv("HPE_SCHED");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 9) v = 0;
-    }
+        const int x = e ? atoi(e) : 0;
+        return (x < 0 || x > 9) ? 0 : x;
+    }();
     return v;
 }
 
 int splitk_enabled() {
-    static int v = -1;
-    if (v < 0) {
+    static const int v = [] {
         const char* e = getenv("HPE_SPLITK");
-        v = e ? atoi(e) : 1;
-    }
+        return e ? atoi(e) : 1;
+    }();
     return v;
 }
 

@@ -508,11 +508,10 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
                                        hipEvent_t ev_a2b0, hipEvent_t ev_a2b1) {
     const MeshWs m = mesh_ws_layout(ws, B, H, W, P);
     const int HW = H * W;
-    static int a2b_valu = -1;
-    if (a2b_valu < 0) {
+    static const int a2b_valu = [] {
         const char* e = getenv("HPE_MESH_A2B");  // "valu": the VALU-only search (A/B comparisons)
-        a2b_valu = (e && e[0] == 'v') ? 1 : 0;
-    }
+        return (e && e[0] == 'v') ? 1 : 0;
+    }();
     if (ev_a2b0) (void)hipEventRecord(ev_a2b0, st);
     if (a2b_valu)
         hipLaunchKernelGGL(nn_a2b_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk);
