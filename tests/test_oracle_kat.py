@@ -189,3 +189,36 @@ def test_lbs_matches_textbook_form(smpl_model):
         for j in range(24):
             out += W[:, j:j + 1] * ((v_posed - J[j]) @ G[j][:3, :3].T + G[j][:3, 3])
         np.testing.assert_allclose(verts[b], out, atol=1e-10)
+
+
+def test_bidirectional_dist_matches_kdtree():
+    """Independent pin for src/ops.py:60-102: the oracle's expanded-form argmin (-2AB^T + |A|^2 + |B|^2) against scipy's
+    cKDTree nearest neighbours on generic (tie-free) float point sets -- L2 from B to its neighbour in A, L1 from A to its
+    neighbour in B -- and the per-image scaling by 3 + 6890 of mesh_reprojection_loss."""
+    from scipy.spatial import cKDTree
+
+    g = np.random.Generator(np.random.Philox(404))
+    A = g.uniform(0, 224, (1500, 2))
+    B = g.uniform(-20, 244, (6890, 2))
+    da, ia = cKDTree(B).query(A)   # A -> nearest in B
+    db, ib = cKDTree(A).query(B)   # B -> nearest in A
+    ref = db.sum() + np.abs(A - B[ia]).sum()
+    got = O.bidirectional_dist(A.astype(np.float64), B.astype(np.float64))
+    assert abs(got - ref) / ref < 1e-12
+    got32 = O.bidirectional_dist(A.astype(np.float32), B.astype(np.float32))
+    assert abs(got32 - ref) / ref < 1e-5
+    # mesh_reprojection_loss on a two-image batch: rows (b, y, x) as tf.where gives them; second image empty-ish (one pixel)
+    seg = np.zeros((2, 224, 224, 1), np.float32)
+    seg[0, 50:90, 60:100] = 1.0
+    seg[1, 10, 20] = 1.0
+    V = g.uniform(0, 224, (2, 6890, 2)).astype(np.float64)
+    pts = O.silhouette_points(seg).astype(np.float64)
+    total = 0.0
+    for i in range(2):
+        rows = pts[pts[:, 0] == i]
+        P = np.stack([rows[:, 2], rows[:, 1]], 1)
+        _, ja = cKDTree(V[i]).query(P)
+        d2, _ = cKDTree(P).query(V[i])
+        total += (d2.sum() + np.abs(P - V[i][ja]).sum()) / (3 + 6890)
+    got = O.mesh_reprojection_loss(pts, V, 2)
+    assert abs(got - total) / total < 1e-12
