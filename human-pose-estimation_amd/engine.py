@@ -153,8 +153,10 @@ class HpeEngine(object):
     # ------------------------------------------------------------------ compute
     DEFAULT_OUTPUTS = ("verts", "joints", "cams", "theta", "J_transformed", "kp2d")
 
-    def forward(self, images, all_stages=False, want=DEFAULT_OUTPUTS):
-        """images [B,224,224,3] cuda float32 -> list (one dict per returned stage) of output tensors."""
+    def forward(self, images, all_stages=False, want=DEFAULT_OUTPUTS, pipelined=False):
+        """images [B,224,224,3] cuda float32 -> list (one dict per returned stage) of output tensors.
+        pipelined=True: hpe_forward_pipelined (the outputs are complete after ``join()``); used by Predictor.predict for inputs
+        larger than config.batch_size, whose chunks then overlap tail and encoder."""
         images = _require_cuda_tensor(images, "images", (224, 224, 3))
         B = images.shape[0]
         n_outs = self.num_stage if all_stages else 1
@@ -164,7 +166,8 @@ class HpeEngine(object):
             t, o = self._alloc_outputs(B, want)
             outs.append(t)
             arr[i] = o
-        _lib.check(self.lib.hpe_forward(self._h, images.data_ptr(), B, arr, n_outs, self._stream()))
+        fwd = self.lib.hpe_forward_pipelined if pipelined else self.lib.hpe_forward
+        _lib.check(fwd(self._h, images.data_ptr(), B, arr, n_outs, self._stream()))
         return outs
 
     def tail_stream(self):

@@ -138,8 +138,11 @@ class Predictor(object):
             raise ValueError("images must be [B,224,224,3] NHWC, got %s" % (tuple(images.shape),))
         B = images.shape[0]
         chunks = []
+        many = B > self.batch_size  # several engine calls: software-pipeline them (tail of chunk k under the encoder of chunk k+1)
         for lo in range(0, B, self.batch_size):
-            chunks.append(self.engine.forward(images[lo : lo + self.batch_size], all_stages=all_stages))
+            chunks.append(self.engine.forward(images[lo : lo + self.batch_size], all_stages=all_stages, pipelined=many))
+        if many:
+            self.engine.join()  # the caller's stream waits for the last tail: results are then ordered like any torch op
         if len(chunks) == 1:
             stages = chunks[0]
         else:

@@ -435,6 +435,11 @@ def test_predictor_surface(assets):
     assert tuple(r["generated_verts"].shape) == (3, 6890, 3) and tuple(r["generated_joints"].shape) == (3, 19, 3)
     for k in ("generated_joints", "generated_verts", "generated_cams", "generated_kp2d", "theta", "J_transformed"):
         assert rel(cpu(r[k]), ref[k]) < TOL, k
+    # chunked inputs go through the pipelined forward: same numbers as chunk-by-chunk serial calls
+    for lo in (0, 2):
+        one = p.predict(img[lo : lo + 2])
+        np.testing.assert_array_equal(cpu(one["generated_verts"]), cpu(r["generated_verts"][lo : lo + 2]))
+        np.testing.assert_array_equal(cpu(one["theta"]), cpu(r["theta"][lo : lo + 2]))
     v, c, j = p.predict_single_image(img[0])
     assert rel(cpu(v), ref["generated_verts"][:1]) < TOL and rel(cpu(j), ref["generated_joints"][:1]) < TOL
     kp = p.proj_fn(r["generated_joints"], r["generated_cams"])
