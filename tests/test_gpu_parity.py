@@ -372,6 +372,22 @@ def test_encoder_features(engine, assets):
     assert rel(f, ref32) < 2e-5
 
 
+@pytest.mark.parametrize("B", [7, 26])
+def test_encoder_features_mid_batches(assets, B):
+    """Batches between the single-frame and the full-size cases: the fused stem switches strip height with the batch (B = 7: 2
+    pooled rows per workgroup, B = 26: 4), the Winograd / direct and split-K decisions change per layer, pixel counts are not
+    multiples of the GEMM tiles.  Two images of each batch against the oracle, all of them against a batch-of-2 run."""
+    e = _engine_with_env(assets, {}, 32)
+    img = synthetic.make_images(B, seed=120 + B)
+    f = cpu(e.encoder(gpu(img)))
+    pick = [0, B - 1]
+    ref = O.resnet50_features(img[pick], assets["enc"])
+    assert rel(f[pick], ref) < 2e-5
+    small = cpu(e.encoder(gpu(img[pick])))
+    assert rel(f[pick], small) < 2e-5
+    e.close()
+
+
 # ------------------------------------------------------------------------------------------- regressor + full path
 def test_regress_stage(engine, assets):
     g = np.random.Generator(np.random.Philox(9))
