@@ -778,6 +778,7 @@ static int finalize_impl(hpe_ctx* c) {
         // per-device function attributes (dynamic LDS above 64 KB) of the Winograd and stem kernels
         HIP_TRY(hpe_wino_init_device());
         HIP_TRY(hpe_stem_fused_init_device());
+        HIP_TRY(hpe_losses_init_device());
     }
     // ---- conv_block (first block of a stage): out = relu(bn2c(W2c . t2) + bn1(W1 . x_strided)).  Both convolutions are 1x1,
     //      so they are ONE GEMM over the concatenated k axis once each BN scale is folded into its weights:

@@ -116,6 +116,7 @@ hipError_t hpe_launch_orth_proj(const float* X, const float* cam, int B, int P, 
 
 // losses.hip
 hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* out, hipStream_t st);
+hipError_t hpe_losses_init_device();  // per-device kernel attributes of the loss kernels
 size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P);
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
                                 hipStream_t st);

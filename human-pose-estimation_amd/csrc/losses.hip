@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "hpe_internal.h"
 
 namespace {
@@ -153,12 +155,26 @@ __global__ __launch_bounds__(256) void nn_a2b_kernel(const float* __restrict__ p
 // In exact arithmetic the choice is the reference's; in fp32 it can differ between candidates whose distances agree to
 // rounding (the reference's own expanded form has that noise: entries ~1e5 px^2 carry ~8e-3 px^2 of rounding).
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+// One element of v_mfma_f32_32x32x2_f32, bit for bit: the matrix core accumulates k = 0, then k = 1, each as a fused
+// multiply-add (tools/probes/mfma_f32_rounding.hip: 0 mismatches in 4.2 M pairs; the other order and a single rounding both
+// differ in ~30 % of them).  The searches recover their winner by recomputing candidates with this and comparing for equality.
+// |b|^2 with two rounded products and a rounded sum (tf.reduce_sum(B * B, 1)); written out so that every kernel that compares
+// matrix-core values for equality feeds the same bits whatever -ffp-contract does to `x * x + y * y`
+// (__fmul_rn / __fadd_rn are plain operators in this HIP and contract like them)
+__device__ __forceinline__ float norm2(float x, float y) {
+#pragma clang fp contract(off)
+    const float xx = x * x;
+    const float yy = y * y;
+    return xx + yy;
+}
+__device__ __forceinline__ float mfma_k2_value(float a0, float b0, float a1, float b1, float c) { return fmaf(a1, b1, fmaf(a0, b0, c)); }
 #define NN_PG 8  // point groups of 32 per wave -> 1024 points per 256-thread block
 // (the explicit waves-per-SIMD bound makes hipcc keep the MFMA results in VGPRs; without it they land in AGPRs and every value
 // costs an extra v_accvgpr_read before the VALU can touch it)
 __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
                                                           const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
-                                                          int nblk) {
+                                                          int nblk, const int* __restrict__ only_flagged) {
+    if (only_flagged && only_flagged[blockIdx.y] == 0) return;  // image already done by the cell-grid search
     __shared__ __attribute__((aligned(16))) float sX[NN_BT];  // -2 bx
     __shared__ __attribute__((aligned(16))) float sY[NN_BT];  // -2 by
     __shared__ __attribute__((aligned(16))) float sN[NN_BT];  // |b|^2 (+inf for padding vertices: never selected)
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __rest
             if (i < n) {
                 bx = Bp[2 * (p0 + i)];
                 by = Bp[2 * (p0 + i) + 1];
-                bn = bx * bx + by * by;
+                bn = norm2(bx, by);
             }
             sX[i] = -2.0f * bx;
             sY[i] = -2.0f * by;
@@ -241,33 +257,351 @@ __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __rest
     float contrib = 0.f;
 #pragma unroll
     for (int g = 0; g < NN_PG; ++g) {
-        // merge the halves (lower value, then lower group id), then recover the vertex inside the winning 16-vertex group
-        const float ob = __shfl_xor(best[g], 32, 64);
-        const int og = __shfl_xor(bgrp[g], 32, 64);
-        const bool take = (ob < best[g]) || (ob == best[g] && og < bgrp[g]);
-        const int grp = take ? og : bgrp[g];
+        // each lane half recovers the vertex inside its winning 16-vertex group (ascending index, strict <), then the halves
+        // merge by (value, vertex index): the two halves of a 32-vertex group interleave in index
         const int idx = base + wave * (32 * NN_PG) + g * 32 + l31;
-        if (hi == 0 && idx < cnt) {
-            const int v0 = (grp >> 1) * 32 + 4 * (grp & 1);
-            float bd = __builtin_inff(), vx = 0.f, vy = 0.f;
+        const int v0 = (bgrp[g] >> 1) * 32 + 4 * (bgrp[g] & 1);
+        float bd = __builtin_inff(), vx = 0.f, vy = 0.f;
+        int bi = 0x7fffffff;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int vi = v0 + (e & 3) + 8 * (e >> 2);  // ascending with e
-                if (vi < P) {
-                    const float bx = Bp[2 * vi], by = Bp[2 * vi + 1];
-                    const float dd = fmaf(-2.0f * bx, px[g], fmaf(-2.0f * by, py[g], bx * bx + by * by));
-                    if (dd < bd) {
-                        bd = dd;
-                        vx = bx;
-                        vy = by;
-                    }
+        for (int e = 0; e < 16; ++e) {
+            const int vi = v0 + (e & 3) + 8 * (e >> 2);  // ascending with e
+            if (vi < P) {
+                const float bx = Bp[2 * vi], by = Bp[2 * vi + 1];
+                const float dd = mfma_k2_value(-2.0f * bx, px[g], -2.0f * by, py[g], norm2(bx, by));
+                if (dd < bd) {
+                    bd = dd;
+                    bi = vi;
+                    vx = bx;
+                    vy = by;
                 }
             }
-            contrib += fabsf(px[g] - vx) + fabsf(py[g] - vy);
         }
+        const float ob = __shfl_xor(best[g], 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        const float ox = __shfl_xor(vx, 32, 64), oy = __shfl_xor(vy, 32, 64);
+        const bool take = (ob < best[g]) || (ob == best[g] && oi < bi);
+        if (hi == 0 && idx < cnt) contrib += fabsf(px[g] - (take ? ox : vx)) + fabsf(py[g] - (take ? oy : vy));
     }
     const float s = block_sum_256(contrib, red);
     if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = s;
+}
+
+// A -> B through a cell grid over the mesh vertices, candidates evaluated on the matrix cores.
+// The silhouette points are integer pixels, so an 8x8-pixel tile is one wave, and the vertices that can be the nearest
+// neighbour of a pixel of the tile lie in the cells around it.  Per (image, slice) workgroup: counting-sort the image's P
+// vertices into CELL x CELL-pixel cells in LDS (vertices outside the image go to the border cells), stage the silhouette
+// bitmap, then every wave walks its tiles: skip the tile if no bit is set, else visit the tile's own cells, then ring after
+// ring of cells around them.  After ring r every vertex not yet seen is farther from a pixel than the pixel's distance m to
+// the edge of the visited block, so a pixel is finished once best + E < m^2 (E bounds the fp32 rounding of the expanded form:
+// the comparison is between COMPUTED values, the same ones a full search compares, so the winner of the full search is always
+// inside the visited set); the wave stops when all its set pixels are finished.
+// Cells of one grid row are contiguous in the sorted array, so a ring is two row segments plus two cells per middle row.  The
+// sorted array is cut into fixed chunks of 32 vertices; a range is evaluated chunk-wise (one v_mfma_f32_32x32x2_f32 per chunk
+// and 32-pixel half tile, operands as in nn_a2b_mfma_kernel) -- vertices of neighbouring cells that share the chunk ride
+// along for free, and a per-wave bitmask keeps a chunk from being evaluated twice.  The winner inside the winning
+// 16-vertex group is recovered once per tile and ordered by (distance, vertex index) = tf.argmin's choice.  Chunks that reach
+// exactly the best fp32 value again (an ulp is ~1e-3 px^2 at these magnitudes, so that is common) are remembered, up to three
+// per pixel, and take part in that recovery; a pixel with more marks its tile, which is then re-evaluated over the same block
+// with an explicit (distance, index) order on the VALU (integer vertex coordinates, duplicated vertices).
+// Typical meshes: 10-30 chunks per tile instead of all 216; a mesh collapsed into a few cells degenerates to the full search.
+#define A2B_NPG 2  // 32-pixel groups per tile (8 x 4 pixels each)
+template <int CELL>
+__global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
+                                                           const float* __restrict__ v2d, int H, int W, int WW, int P, int Gx, int Gy,
+                                                           float* __restrict__ partial, int nblk, int nslots, int* __restrict__ full_search,
+                                                           int min_cells, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char grid_smem[];
+    const int NC = Gx * Gy;
+    const int Ppad = (P + 31) & ~31;
+    float* sX = reinterpret_cast<float*>(grid_smem);  // -2 x, sorted by cell
+    float* sY = sX + Ppad;                            // -2 y
+    float* sN = sY + Ppad;                            // |b|^2 (+inf in the padding)
+    int* sI = reinterpret_cast<int*>(sN + Ppad);      // vertex index
+    int* sStart = sI + Ppad;                          // [NC + 1]
+    int* sCur = sStart + NC + 1;                      // [NC] histogram, then scatter cursors (+1 pad keeps sbits 8-byte aligned)
+    unsigned long long* sbits = reinterpret_cast<unsigned long long*>(sCur + NC + 1);  // [H][WW]
+    __shared__ int wtot[16];
+    __shared__ float red[16];
+    __shared__ int s_occupied;
+    const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cnt = counts[b];
+    if (slice == 0)
+        for (int i = nslice + t; i < nslots; i += 1024) partial[(size_t)b * nblk + i] = 0.f;
+    if (cnt == 0) {
+        if (t == 0) {
+            partial[(size_t)b * nblk + slice] = 0.f;
+            if (slice == 0) full_search[b] = 0;
+        }
+        return;
+    }
+    if (t == 0) s_occupied = 0;
+    for (int i = t; i < NC; i += 1024) sCur[i] = 0;
+    for (int i = t; i < H * WW; i += 1024) sbits[i] = bits[(size_t)b * H * WW + i];
+    for (int i = P + t; i < Ppad; i += 1024) {
+        sX[i] = 0.f;
+        sY[i] = 0.f;
+        sN[i] = __builtin_inff();
+        sI[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    const float* Bp = v2d + (size_t)b * P * 2;
+    const float gxm = (float)(Gx - 1), gym = (float)(Gy - 1);
+    auto cell_of = [&](float x, float y) {
+        // fmaxf(NaN, 0) = 0: a NaN vertex lands in a valid cell and never wins a comparison, as in the full search
+        const int cx = (int)fminf(fmaxf(floorf(x * (1.0f / CELL)), 0.f), gxm);
+        const int cy = (int)fminf(fmaxf(floorf(y * (1.0f / CELL)), 0.f), gym);
+        return cy * Gx + cx;
+    };
+    for (int i = t; i < P; i += 1024) atomicAdd(&sCur[cell_of(Bp[2 * i], Bp[2 * i + 1])], 1);
+    __syncthreads();
+    {
+        // exclusive scan of the histogram: `per` consecutive cells per thread, wave scan, 16 wave totals
+        const int per = (NC + 1023) / 1024;
+        int loc = 0;
+        for (int k = 0; k < per; ++k) {
+            const int idx = t * per + k;
+            if (idx < NC) loc += sCur[idx];
+        }
+        {
+            int occ = 0;
+            for (int k = 0; k < per; ++k) {
+                const int idx = t * per + k;
+                if (idx < NC && sCur[idx] > 0) ++occ;
+            }
+            if (occ) atomicAdd(&s_occupied, occ);
+        }
+        int inc = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += n;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int run = inc - loc;
+        for (int w = 0; w < wave; ++w) run += wtot[w];
+        for (int k = 0; k < per; ++k) {
+            const int idx = t * per + k;
+            if (idx < NC) {
+                const int c = sCur[idx];
+                sStart[idx] = run;
+                sCur[idx] = run;
+                run += c;
+            }
+        }
+        if (t == 0) sStart[NC] = P;
+    }
+    __syncthreads();
+    // A mesh concentrated in a few cells leaves nothing to prune (every tile ends up visiting most chunks, at a higher cost per
+    // chunk than the full search): such an image is left to nn_a2b_mfma_kernel, launched behind this kernel for flagged images.
+    const bool concentrated = s_occupied < min_cells;
+    if (t == 0 && slice == 0) full_search[b] = concentrated ? 1 : 0;
+    if (concentrated) return;
+    // scatter; the order inside a cell is whatever the atomics give, which decides nothing below: the search returns the lowest
+    // vertex index among the vertices at the minimal computed distance, and that is a property of the set
+    for (int i = t; i < P; i += 1024) {
+        const float x = Bp[2 * i], y = Bp[2 * i + 1];
+        const int pos = atomicAdd(&sCur[cell_of(x, y)], 1);
+        sX[pos] = -2.0f * x;
+        sY[pos] = -2.0f * y;
+        sN[pos] = norm2(x, y);
+        sI[pos] = i;
+    }
+    __syncthreads();
+    if (dbg == 1) {
+        if (t == 0) partial[(size_t)b * nblk + slice] = 0.f;
+        return;
+    }
+    constexpr int T = 8 / CELL;  // cells per tile edge
+    constexpr float NONE = 3.0e38f;
+    const int TX = (W + 7) >> 3, TY = (H + 7) >> 3, NT = TX * TY;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int lx = l31 & 7, ly = l31 >> 3;
+    float contrib = 0.f;
+    for (int tile = slice * 16 + wave; tile < NT; tile += 16 * nslice) {
+        const int ty = tile / TX, tx = tile - ty * TX;
+        float px[A2B_NPG], py[A2B_NPG], aa[A2B_NPG], best[A2B_NPG];
+        int bchunk[A2B_NPG][4];  // [0]: chunk of the best value; [1..3]: later chunks that reached exactly the same value
+        int ntie[A2B_NPG];
+        bool active[A2B_NPG];
+        bool any_active = false;
+#pragma unroll
+        for (int g = 0; g < A2B_NPG; ++g) {
+            const int col = tx * 8 + lx, row = ty * 8 + 4 * g + ly;
+            active[g] = (col < W && row < H) ? ((sbits[row * WW + (col >> 6)] >> (col & 63)) & 1ull) : false;
+            any_active |= active[g];
+            px[g] = (float)col;
+            py[g] = (float)row;
+            aa[g] = px[g] * px[g] + py[g] * py[g];
+            best[g] = NONE;
+            bchunk[g][0] = bchunk[g][1] = bchunk[g][2] = bchunk[g][3] = 0;
+            ntie[g] = 0;
+        }
+        if (__ballot(any_active) == 0ull) continue;
+        bool overflow = false;  // more than three chunks tied with the best: the tile takes the explicit (distance, index) pass
+        int vmask = 0;  // lane w holds bits 32w .. 32w+31 of the wave's visited-chunk set
+        auto scan = [&](int c0, int c1) {
+            const int s = __builtin_amdgcn_readfirstlane(sStart[c0]), e = __builtin_amdgcn_readfirstlane(sStart[c1 + 1]);
+            if (e <= s) return;
+            for (int k = s >> 5; k <= (e - 1) >> 5; ++k) {
+                const int word = __builtin_amdgcn_readlane(vmask, k >> 5);
+                if ((word >> (k & 31)) & 1) continue;
+                vmask |= (lane == (k >> 5)) ? (1 << (k & 31)) : 0;
+                const float a = hi ? sY[32 * k + l31] : sX[32 * k + l31];
+                f32x16_t qz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 q = *reinterpret_cast<const float4*>(&sN[32 * k + 8 * j + 4 * hi]);
+                    qz[4 * j] = q.x;
+                    qz[4 * j + 1] = q.y;
+                    qz[4 * j + 2] = q.z;
+                    qz[4 * j + 3] = q.w;
+                }
+                f32x16_t d[A2B_NPG];
+#pragma unroll
+                for (int g = 0; g < A2B_NPG; ++g) d[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hi ? py[g] : px[g], qz, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < A2B_NPG; ++g) {
+                    const float m0 = fminf(fminf(d[g][0], d[g][1]), d[g][2]);
+                    const float m1 = fminf(fminf(d[g][3], d[g][4]), d[g][5]);
+                    const float m2 = fminf(fminf(d[g][6], d[g][7]), d[g][8]);
+                    const float m3 = fminf(fminf(d[g][9], d[g][10]), d[g][11]);
+                    const float m4 = fminf(fminf(d[g][12], d[g][13]), d[g][14]);
+                    const float m5 = fminf(fminf(m0, m1), d[g][15]);
+                    const float m = fminf(fminf(m2, m3), fminf(m4, m5));
+                    const bool lt = m < best[g];
+                    const bool eq = m == best[g];
+                    best[g] = fminf(m, best[g]);
+                    bchunk[g][0] = lt ? k : bchunk[g][0];
+                    ntie[g] = lt ? 0 : ntie[g];
+                    if (__any(eq)) {
+                        // equal fp32 values in two chunks (at ~1e4 px^2 an ulp is 1e-3 px^2: not rare); vertex indices decide
+                        // at the end, so the chunk is remembered
+                        ntie[g] += eq ? 1 : 0;
+                        bchunk[g][1] = (eq && ntie[g] == 1) ? k : bchunk[g][1];
+                        bchunk[g][2] = (eq && ntie[g] == 2) ? k : bchunk[g][2];
+                        bchunk[g][3] = (eq && ntie[g] == 3) ? k : bchunk[g][3];
+                    }
+                }
+            }
+        };
+        const int X0 = tx * T, Y0 = ty * T, X1 = min(X0 + T - 1, Gx - 1), Y1 = min(Y0 + T - 1, Gy - 1);
+        int xa, xb, ya, yb;
+        for (int r = 0;; ++r) {
+            xa = X0 - r, xb = X1 + r, ya = Y0 - r, yb = Y1 + r;
+            const int xac = max(xa, 0), xbc = min(xb, Gx - 1), yac = max(ya, 0), ybc = min(yb, Gy - 1);
+            for (int cy = yac; cy <= ybc; ++cy) {
+                if (r == 0 || cy == ya || cy == yb) {
+                    scan(cy * Gx + xac, cy * Gx + xbc);
+                } else {
+                    if (xa >= 0) scan(cy * Gx + xa, cy * Gx + xa);
+                    if (xb < Gx) scan(cy * Gx + xb, cy * Gx + xb);
+                }
+            }
+            if (xa <= 0 && xb >= Gx - 1 && ya <= 0 && yb >= Gy - 1) break;  // every cell visited
+            bool done = true;
+#pragma unroll
+            for (int g = 0; g < A2B_NPG; ++g) {
+                // distance from the pixel to the nearest side of the visited block that still has cells beyond it
+                float m = __builtin_inff();
+                if (xa > 0) m = fminf(m, px[g] - (float)(xa * CELL));
+                if (xb < Gx - 1) m = fminf(m, (float)((xb + 1) * CELL) - px[g]);
+                if (ya > 0) m = fminf(m, py[g] - (float)(ya * CELL));
+                if (yb < Gy - 1) m = fminf(m, (float)((yb + 1) * CELL) - py[g]);
+                const float m2 = m * m;
+                const float bm = fminf(best[g], __shfl_xor(best[g], 32, 64));  // the two lane halves see different vertex rows
+                // |error of a computed distance| <= ~1e-6 (3 |a|^2 + 2 d^2) for any candidate at true distance d >= m
+                done = done && (!active[g] || ((bm + aa[g]) + (3e-6f * aa[g] + 2e-6f * m2) < m2));
+            }
+            if (dbg != 3 && __all(done)) break;
+        }
+        // winner inside the winning 16-vertex groups of each lane half (the best chunk and the chunks tied with it), then the
+        // better half; order (distance, vertex index)
+        float wx[A2B_NPG], wy[A2B_NPG];
+#pragma unroll
+        for (int g = 0; g < A2B_NPG; ++g) {
+            float vx = 0.f, vy = 0.f;
+            int bi = 0x7fffffff;
+            const int nt = (best[g] < NONE) ? min(ntie[g], 3) + 1 : 0;
+            overflow |= ntie[g] > 3 && active[g];
+            for (int a = 0; a < 4; ++a) {
+                if (!__any(a < nt)) break;
+                if (a < nt) {
+                    const int ck = a == 0 ? bchunk[g][0] : (a == 1 ? bchunk[g][1] : (a == 2 ? bchunk[g][2] : bchunk[g][3]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p0 = 32 * ck + 8 * j + 4 * hi;
+                        const float4 qx = *reinterpret_cast<const float4*>(&sX[p0]);
+                        const float4 qy = *reinterpret_cast<const float4*>(&sY[p0]);
+                        const float4 qn = *reinterpret_cast<const float4*>(&sN[p0]);
+                        const int4 qi = *reinterpret_cast<const int4*>(&sI[p0]);
+                        const float ex[4] = {qx.x, qx.y, qx.z, qx.w}, ey[4] = {qy.x, qy.y, qy.z, qy.w}, en[4] = {qn.x, qn.y, qn.z, qn.w};
+                        const int ei[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float dd = mfma_k2_value(ex[i], px[g], ey[i], py[g], en[i]);
+                            if (dd == best[g] && ei[i] < bi) {
+                                bi = ei[i];
+                                vx = -0.5f * ex[i];
+                                vy = -0.5f * ey[i];
+                            }
+                        }
+                    }
+                }
+            }
+            const float ob = __shfl_xor(best[g], 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            const float ox = __shfl_xor(vx, 32, 64), oy = __shfl_xor(vy, 32, 64);
+            const bool take = (ob < best[g]) || (ob == best[g] && oi < bi);
+            wx[g] = take ? ox : vx;
+            wy[g] = take ? oy : vy;
+        }
+        if (dbg != 2 && __any(overflow)) {
+            // more tied chunks than the lane keeps: the same block again with an explicit (distance, vertex index) order
+            float bd[A2B_NPG];
+            int bi[A2B_NPG];
+#pragma unroll
+            for (int g = 0; g < A2B_NPG; ++g) {
+                bd[g] = __builtin_inff();
+                bi[g] = 0x7fffffff;
+                wx[g] = wy[g] = 0.f;
+            }
+            const int xac = max(xa, 0), xbc = min(xb, Gx - 1), yac = max(ya, 0), ybc = min(yb, Gy - 1);
+            for (int cy = yac; cy <= ybc; ++cy) {
+                const int s = __builtin_amdgcn_readfirstlane(sStart[cy * Gx + xac]);
+                const int e = __builtin_amdgcn_readfirstlane(sStart[cy * Gx + xbc + 1]);
+                for (int j = s; j < e; ++j) {
+                    const float ex = sX[j], ey = sY[j], en = sN[j];
+                    const int ei = sI[j];
+#pragma unroll
+                    for (int g = 0; g < A2B_NPG; ++g) {
+                        const float dd = mfma_k2_value(ex, px[g], ey, py[g], en);
+                        const bool lt = dd < bd[g] || (dd == bd[g] && ei < bi[g]);
+                        bd[g] = lt ? dd : bd[g];
+                        bi[g] = lt ? ei : bi[g];
+                        wx[g] = lt ? -0.5f * ex : wx[g];
+                        wy[g] = lt ? -0.5f * ey : wy[g];
+                    }
+                }
+            }
+        }
+        if (hi == 0) {
+#pragma unroll
+            for (int g = 0; g < A2B_NPG; ++g)
+                if (active[g]) contrib += fabsf(px[g] - wx[g]) + fabsf(py[g] - wy[g]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
+    if (lane == 0) red[wave] = contrib;
+    __syncthreads();
+    if (t == 0) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        partial[(size_t)b * nblk + slice] = s;
+    }
 }
 
 // direction B -> A: every mesh vertex finds its nearest silhouette point, contributes ||b - a*||_2.
@@ -450,6 +784,17 @@ __global__ __launch_bounds__(1024) void mesh_loss_finish_kernel(const float* __r
 
 }  // namespace
 
+#define A2B_CELL 8
+#define A2B_GRID_MAX_LDS (156 * 1024)
+static size_t a2b_grid_lds_bytes(int H, int WW, int P, int Gx, int Gy) {
+    return (size_t)((P + 31) & ~31) * 16 + (size_t)(2 * Gx * Gy + 2) * 4 + (size_t)H * WW * 8;
+}
+
+hipError_t hpe_losses_init_device() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&nn_a2b_grid_kernel<A2B_CELL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               A2B_GRID_MAX_LDS);
+}
+
 hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(kp_loss_kernel, dim3(1), dim3(256), 0, st, gt, pred, n, out);
     return hipGetLastError();
@@ -459,7 +804,7 @@ size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P) {
     const int HW = H * W;
     const int nblk = (HW + 1023) / 1024 + (P + 255) / 256;
     const size_t bitmap_floats = (size_t)B * H * ((W + 63) / 64) * 2;
-    return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64 + bitmap_floats + 16;
+    return (size_t)B * HW * 2 + (size_t)B * nblk + (size_t)B + 64 + bitmap_floats + 16 + (size_t)B;
 }
 
 // Workspace layout shared by the two halves of the mesh loss
@@ -468,6 +813,7 @@ struct MeshWs {
     float* partial;
     int* counts;
     unsigned long long* bits;
+    int* full_search;  // [B] per image: 1 = the pixel -> vertex search of this image is done by the full search
     int nA, nB, nblk, WW;
     bool grid_path;
 };
@@ -487,6 +833,7 @@ static MeshWs mesh_ws_layout(float* ws, int B, int H, int W, int P) {
     size_t off = (size_t)B * HW * 2 + (size_t)B * m.nblk + (size_t)B + 2;
     off = (off + 1) & ~(size_t)1;
     m.bits = reinterpret_cast<unsigned long long*>(ws + off);
+    m.full_search = reinterpret_cast<int*>(ws + off + (size_t)B * H * m.WW * 2);
     return m;
 }
 
@@ -508,15 +855,41 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
                                        hipEvent_t ev_a2b0, hipEvent_t ev_a2b1) {
     const MeshWs m = mesh_ws_layout(ws, B, H, W, P);
     const int HW = H * W;
-    static const int a2b_valu = [] {
-        const char* e = getenv("HPE_MESH_A2B");  // "valu": the VALU-only search (A/B comparisons)
-        return (e && e[0] == 'v') ? 1 : 0;
+    // HPE_MESH_A2B: "grid" (default: cell-grid search), "mfma" / "valu" (the full searches, for A/B comparisons)
+    static const int a2b_mode = [] {
+        const char* e = getenv("HPE_MESH_A2B");
+        return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0));
+    }();
+    // images whose vertices occupy fewer cells than this go to the full search (0: never)
+    static const int a2b_min_cells = [] {
+        const char* e = getenv("HPE_MESH_A2B_MINCELLS");
+        return e ? atoi(e) : 40;
+    }();
+    static const int a2b_dbg = [] {
+        const char* e = getenv("HPE_MESH_A2B_DBG");
+        return e ? atoi(e) : 0;
+    }();
+    static const int a2b_slices = [] {
+        const char* e = getenv("HPE_MESH_A2B_SLICES");  // workgroups per image of the grid search (0: about 512 / B)
+        return e ? atoi(e) : 0;
     }();
     if (ev_a2b0) (void)hipEventRecord(ev_a2b0, st);
-    if (a2b_valu)
+    const int Gx = (W + A2B_CELL - 1) / A2B_CELL, Gy = (H + A2B_CELL - 1) / A2B_CELL;
+    const size_t grid_lds = a2b_grid_lds_bytes(H, m.WW, P, Gx, Gy);
+    if (a2b_mode == 0 && m.grid_path && grid_lds <= A2B_GRID_MAX_LDS) {
+        int nslice = a2b_slices > 0 ? a2b_slices : (512 + B - 1) / B;
+        nslice = std::max(1, std::min(nslice, m.nA));
+        hipLaunchKernelGGL(nn_a2b_grid_kernel<A2B_CELL>, dim3(nslice, B), dim3(1024), grid_lds, st, m.bits, m.counts, v2d, H, W, m.WW, P,
+                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, a2b_min_cells, a2b_dbg);
+        hipError_t eg = hipGetLastError();
+        if (eg != hipSuccess) return eg;
+        hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk,
+                               (const int*)m.full_search);
+    } else if (a2b_mode == 1)
         hipLaunchKernelGGL(nn_a2b_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk);
     else
-        hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk);
+        hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk,
+                           (const int*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_a2b1) (void)hipEventRecord(ev_a2b1, st);
