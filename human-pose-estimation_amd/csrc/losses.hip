@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __rest
 // per pixel, and take part in that recovery; a pixel with more marks its tile, which is then re-evaluated over the same block
 // with an explicit (distance, index) order on the VALU (integer vertex coordinates, duplicated vertices).
 // Typical meshes: 10-30 chunks per tile instead of all 216; a mesh collapsed into a few cells degenerates to the full search.
-#define A2B_NPG 2  // 32-pixel groups per tile (8 x 4 pixels each)
-template <int CELL>
+// NPG: 32-pixel groups (8 x 4 pixels) per tile, stacked vertically; the tile is 8 x 4 NPG pixels
+template <int CELL, int NPG>
 __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
                                                            const float* __restrict__ v2d, int H, int W, int WW, int P, int Gx, int Gy,
                                                            float* __restrict__ partial, int nblk, int nslots, int* __restrict__ full_search,
@@ -321,7 +321,9 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
     int* sStart = sI + Ppad;                          // [NC + 1]
     int* sCur = sStart + NC + 1;                      // [NC] histogram, then scatter cursors (+1 pad keeps sbits 8-byte aligned)
     unsigned long long* sbits = reinterpret_cast<unsigned long long*>(sCur + NC + 1);  // [H][WW]
+    float* sTile = reinterpret_cast<float*>(sbits + H * WW);                            // [tiles of this workgroup]
     __shared__ int wtot[16];
+    __shared__ int s_next;
     __shared__ float red[16];
     __shared__ int s_occupied;
     const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         }
         return;
     }
-    if (t == 0) s_occupied = 0;
+    if (t == 0) s_occupied = s_next = 0;
     for (int i = t; i < NC; i += 1024) sCur[i] = 0;
     for (int i = t; i < H * WW; i += 1024) sbits[i] = bits[(size_t)b * H * WW + i];
     for (int i = P + t; i < Ppad; i += 1024) {
@@ -414,22 +416,33 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         if (t == 0) partial[(size_t)b * nblk + slice] = 0.f;
         return;
     }
-    constexpr int T = 8 / CELL;  // cells per tile edge
+    constexpr int TH = 4 * NPG;                  // tile height in pixels
+    constexpr int TCX = 8 / CELL, TCY = TH / CELL;  // cells per tile edge
+    static_assert(8 % CELL == 0 && TH % CELL == 0, "tiles are whole cells");
     constexpr float NONE = 3.0e38f;
-    const int TX = (W + 7) >> 3, TY = (H + 7) >> 3, NT = TX * TY;
+    const int TX = (W + 7) >> 3, TY = (H + TH - 1) / TH, NT = TX * TY;
     const int hi = lane >> 5, l31 = lane & 31;
     const int lx = l31 & 7, ly = l31 >> 3;
-    float contrib = 0.f;
-    for (int tile = slice * 16 + wave; tile < NT; tile += 16 * nslice) {
+    // tiles q * nslice + slice of this workgroup are handed out through an LDS counter (their cost varies with the distance to
+    // the mesh); every tile leaves its sum in sTile[q], summed in a fixed order at the end, so the result does not depend on
+    // which wave took which tile
+    const int nq = (NT - slice + nslice - 1) / nslice;
+    auto next_tile = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&s_next, 1);
+        return __shfl(v, 0, 64);
+    };
+    auto tile_sum = [&](int q) -> float {
+        const int tile = q * nslice + slice;
         const int ty = tile / TX, tx = tile - ty * TX;
-        float px[A2B_NPG], py[A2B_NPG], aa[A2B_NPG], best[A2B_NPG];
-        int bchunk[A2B_NPG][4];  // [0]: chunk of the best value; [1..3]: later chunks that reached exactly the same value
-        int ntie[A2B_NPG];
-        bool active[A2B_NPG];
+        float px[NPG], py[NPG], aa[NPG], best[NPG];
+        int bchunk[NPG][4];  // [0]: chunk of the best value; [1..3]: later chunks that reached exactly the same value
+        int ntie[NPG];
+        bool active[NPG];
         bool any_active = false;
 #pragma unroll
-        for (int g = 0; g < A2B_NPG; ++g) {
-            const int col = tx * 8 + lx, row = ty * 8 + 4 * g + ly;
+        for (int g = 0; g < NPG; ++g) {
+            const int col = tx * 8 + lx, row = ty * TH + 4 * g + ly;
             active[g] = (col < W && row < H) ? ((sbits[row * WW + (col >> 6)] >> (col & 63)) & 1ull) : false;
             any_active |= active[g];
             px[g] = (float)col;
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
             bchunk[g][0] = bchunk[g][1] = bchunk[g][2] = bchunk[g][3] = 0;
             ntie[g] = 0;
         }
-        if (__ballot(any_active) == 0ull) continue;
+        if (__ballot(any_active) == 0ull) return 0.f;
         bool overflow = false;  // more than three chunks tied with the best: the tile takes the explicit (distance, index) pass
         int vmask = 0;  // lane w holds bits 32w .. 32w+31 of the wave's visited-chunk set
         auto scan = [&](int c0, int c1) {
@@ -459,11 +472,11 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                     qz[4 * j + 2] = q.z;
                     qz[4 * j + 3] = q.w;
                 }
-                f32x16_t d[A2B_NPG];
+                f32x16_t d[NPG];
 #pragma unroll
-                for (int g = 0; g < A2B_NPG; ++g) d[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hi ? py[g] : px[g], qz, 0, 0, 0);
+                for (int g = 0; g < NPG; ++g) d[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hi ? py[g] : px[g], qz, 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < A2B_NPG; ++g) {
+                for (int g = 0; g < NPG; ++g) {
                     const float m0 = fminf(fminf(d[g][0], d[g][1]), d[g][2]);
                     const float m1 = fminf(fminf(d[g][3], d[g][4]), d[g][5]);
                     const float m2 = fminf(fminf(d[g][6], d[g][7]), d[g][8]);
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                 }
             }
         };
-        const int X0 = tx * T, Y0 = ty * T, X1 = min(X0 + T - 1, Gx - 1), Y1 = min(Y0 + T - 1, Gy - 1);
+        const int X0 = tx * TCX, Y0 = ty * TCY, X1 = min(X0 + TCX - 1, Gx - 1), Y1 = min(Y0 + TCY - 1, Gy - 1);
         int xa, xb, ya, yb;
         for (int r = 0;; ++r) {
             xa = X0 - r, xb = X1 + r, ya = Y0 - r, yb = Y1 + r;
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
             if (xa <= 0 && xb >= Gx - 1 && ya <= 0 && yb >= Gy - 1) break;  // every cell visited
             bool done = true;
 #pragma unroll
-            for (int g = 0; g < A2B_NPG; ++g) {
+            for (int g = 0; g < NPG; ++g) {
                 // distance from the pixel to the nearest side of the visited block that still has cells beyond it
                 float m = __builtin_inff();
                 if (xa > 0) m = fminf(m, px[g] - (float)(xa * CELL));
@@ -519,9 +532,9 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         }
         // winner inside the winning 16-vertex groups of each lane half (the best chunk and the chunks tied with it), then the
         // better half; order (distance, vertex index)
-        float wx[A2B_NPG], wy[A2B_NPG];
+        float wx[NPG], wy[NPG];
 #pragma unroll
-        for (int g = 0; g < A2B_NPG; ++g) {
+        for (int g = 0; g < NPG; ++g) {
             float vx = 0.f, vy = 0.f;
             int bi = 0x7fffffff;
             const int nt = (best[g] < NONE) ? min(ntie[g], 3) + 1 : 0;
@@ -560,10 +573,10 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         }
         if (dbg != 2 && __any(overflow)) {
             // more tied chunks than the lane keeps: the same block again with an explicit (distance, vertex index) order
-            float bd[A2B_NPG];
-            int bi[A2B_NPG];
+            float bd[NPG];
+            int bi[NPG];
 #pragma unroll
-            for (int g = 0; g < A2B_NPG; ++g) {
+            for (int g = 0; g < NPG; ++g) {
                 bd[g] = __builtin_inff();
                 bi[g] = 0x7fffffff;
                 wx[g] = wy[g] = 0.f;
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                     const float ex = sX[j], ey = sY[j], en = sN[j];
                     const int ei = sI[j];
 #pragma unroll
-                    for (int g = 0; g < A2B_NPG; ++g) {
+                    for (int g = 0; g < NPG; ++g) {
                         const float dd = mfma_k2_value(ex, px[g], ey, py[g], en);
                         const bool lt = dd < bd[g] || (dd == bd[g] && ei < bi[g]);
                         bd[g] = lt ? dd : bd[g];
@@ -587,15 +600,26 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                 }
             }
         }
+        float contrib = 0.f;
         if (hi == 0) {
 #pragma unroll
-            for (int g = 0; g < A2B_NPG; ++g)
+            for (int g = 0; g < NPG; ++g)
                 if (active[g]) contrib += fabsf(px[g] - wx[g]) + fabsf(py[g] - wy[g]);
         }
-    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
-    if (lane == 0) red[wave] = contrib;
+        for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
+        return contrib;
+    };
+    for (int q = next_tile(); q < nq; q = next_tile()) {
+        const float c = tile_sum(q);
+        if (lane == 0) sTile[q] = c;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int q = t; q < nq; q += 1024) acc += sTile[q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (t == 0) {
         float s = 0.f;
@@ -784,15 +808,24 @@ __global__ __launch_bounds__(1024) void mesh_loss_finish_kernel(const float* __r
 
 }  // namespace
 
-#define A2B_CELL 8
 #define A2B_GRID_MAX_LDS (156 * 1024)
-static size_t a2b_grid_lds_bytes(int H, int WW, int P, int Gx, int Gy) {
-    return (size_t)((P + 31) & ~31) * 16 + (size_t)(2 * Gx * Gy + 2) * 4 + (size_t)H * WW * 8;
+static size_t a2b_grid_lds_bytes(int H, int W, int WW, int P, int Gx, int Gy) {
+    return (size_t)((P + 31) & ~31) * 16 + (size_t)(2 * Gx * Gy + 2) * 4 + (size_t)H * WW * 8 + (size_t)((W + 7) / 8) * ((H + 7) / 8) * 4;
 }
 
+typedef void (*A2bGridKernel)(const unsigned long long*, const int*, const float*, int, int, int, int, int, int, float*, int, int, int*, int, int);
+// (cell edge, 32-pixel groups per tile) variants; [0] is the default
+static const struct {
+    int cell, npg;
+    A2bGridKernel fn;
+} a2b_grid_variants[] = {{8, 2, nn_a2b_grid_kernel<8, 2>}, {4, 2, nn_a2b_grid_kernel<4, 2>}};
+
 hipError_t hpe_losses_init_device() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&nn_a2b_grid_kernel<A2B_CELL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               A2B_GRID_MAX_LDS);
+    for (const auto& v : a2b_grid_variants) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, A2B_GRID_MAX_LDS);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* out, hipStream_t st) {
@@ -874,13 +907,24 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
         return e ? atoi(e) : 0;
     }();
     if (ev_a2b0) (void)hipEventRecord(ev_a2b0, st);
-    const int Gx = (W + A2B_CELL - 1) / A2B_CELL, Gy = (H + A2B_CELL - 1) / A2B_CELL;
-    const size_t grid_lds = a2b_grid_lds_bytes(H, m.WW, P, Gx, Gy);
+    static const int a2b_variant = [] {
+        // cell edge 8 (default) / 4 pixels.  Measured on the config-5 inputs (tools/mesh_loss_bench.py, ms per loss call, B = 256):
+        // 8 px cells 0.83 / 0.66 / 0.41, 4 px cells 0.99 / 0.76 / 0.39, 8 x 16-pixel tiles (4 groups per wave) 0.90 / 0.70 / 0.43
+        const char* c = getenv("HPE_MESH_A2B_CELL");
+        const int cell = c ? atoi(c) : 8;
+        for (int i = 0; i < 2; ++i)
+            if (a2b_grid_variants[i].cell == cell) return i;
+        return 0;
+    }();
+    const int cell = a2b_grid_variants[a2b_variant].cell;
+    const int Gx = (W + cell - 1) / cell, Gy = (H + cell - 1) / cell;
+    const size_t grid_lds = a2b_grid_lds_bytes(H, W, m.WW, P, Gx, Gy);
     if (a2b_mode == 0 && m.grid_path && grid_lds <= A2B_GRID_MAX_LDS) {
         int nslice = a2b_slices > 0 ? a2b_slices : (512 + B - 1) / B;
         nslice = std::max(1, std::min(nslice, m.nA));
-        hipLaunchKernelGGL(nn_a2b_grid_kernel<A2B_CELL>, dim3(nslice, B), dim3(1024), grid_lds, st, m.bits, m.counts, v2d, H, W, m.WW, P,
-                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, a2b_min_cells, a2b_dbg);
+        const int min_cells = a2b_min_cells * (64 / (cell * cell));  // the knob is in 8 x 8-pixel cells
+        hipLaunchKernelGGL(a2b_grid_variants[a2b_variant].fn, dim3(nslice, B), dim3(1024), grid_lds, st, m.bits, m.counts, v2d, H, W, m.WW, P,
+                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, min_cells, a2b_dbg);
         hipError_t eg = hipGetLastError();
         if (eg != hipSuccess) return eg;
         hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk,

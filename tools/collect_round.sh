@@ -14,4 +14,6 @@ HPE_STEM_FUSED=0 HPE_DUAL=0 HPE_BF16_RULES=0 python bench.py --steps 20 --warmup
 HPE_BENCH_LAYERS=1 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --sustain 0 2>$OUT/layers_fp32.txt > /dev/null
 HPE_BENCH_LAYERS=1 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --sustain 0 --encoder-dtype bf16 2>$OUT/layers_bf16.txt > /dev/null
 python tools/latency_bench.py 2>/dev/null | grep "B=" > $OUT/latency_small_batch.txt
+for m in grid mfma; do echo "== HPE_MESH_A2B=$m"; HPE_MESH_A2B=$m python tools/mesh_loss_bench.py 2>/dev/null; done > $OUT/mesh_loss_search.txt
+HPE_MESH_A2B=mfma python bench.py --steps 10 --warmup 3 --config5 --cpu-sample 0 --sustain 0 2>/dev/null > $OUT/bench_config5_full_search.json
 for f in $OUT/bench_*.json; do echo $f; cut -c1-170 $f; done
