@@ -310,7 +310,7 @@ template <int CELL, int NPG>
 __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
                                                            const float* __restrict__ v2d, int H, int W, int WW, int P, int Gx, int Gy,
                                                            float* __restrict__ partial, int nblk, int nslots, int* __restrict__ full_search,
-                                                           int min_cells, int dbg) {
+                                                           int min_cells) {
     extern __shared__ __attribute__((aligned(16))) unsigned char grid_smem[];
     const int NC = Gx * Gy;
     const int Ppad = (P + 31) & ~31;
@@ -412,10 +412,6 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         sI[pos] = i;
     }
     __syncthreads();
-    if (dbg == 1) {
-        if (t == 0) partial[(size_t)b * nblk + slice] = 0.f;
-        return;
-    }
     constexpr int TH = 4 * NPG;                  // tile height in pixels
     constexpr int TCX = 8 / CELL, TCY = TH / CELL;  // cells per tile edge
     static_assert(8 % CELL == 0 && TH % CELL == 0, "tiles are whole cells");
@@ -528,7 +524,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                 // |error of a computed distance| <= ~1e-6 (3 |a|^2 + 2 d^2) for any candidate at true distance d >= m
                 done = done && (!active[g] || ((bm + aa[g]) + (3e-6f * aa[g] + 2e-6f * m2) < m2));
             }
-            if (dbg != 3 && __all(done)) break;
+            if (__all(done)) break;
         }
         // winner inside the winning 16-vertex groups of each lane half (the best chunk and the chunks tied with it), then the
         // better half; order (distance, vertex index)
@@ -571,7 +567,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
             wx[g] = take ? ox : vx;
             wy[g] = take ? oy : vy;
         }
-        if (dbg != 2 && __any(overflow)) {
+        if (__any(overflow)) {
             // more tied chunks than the lane keeps: the same block again with an explicit (distance, vertex index) order
             float bd[NPG];
             int bi[NPG];
@@ -813,7 +809,7 @@ static size_t a2b_grid_lds_bytes(int H, int W, int WW, int P, int Gx, int Gy) {
     return (size_t)((P + 31) & ~31) * 16 + (size_t)(2 * Gx * Gy + 2) * 4 + (size_t)H * WW * 8 + (size_t)((W + 7) / 8) * ((H + 7) / 8) * 4;
 }
 
-typedef void (*A2bGridKernel)(const unsigned long long*, const int*, const float*, int, int, int, int, int, int, float*, int, int, int*, int, int);
+typedef void (*A2bGridKernel)(const unsigned long long*, const int*, const float*, int, int, int, int, int, int, float*, int, int, int*, int);
 // (cell edge, 32-pixel groups per tile) variants; [0] is the default
 static const struct {
     int cell, npg;
@@ -898,10 +894,6 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
         const char* e = getenv("HPE_MESH_A2B_MINCELLS");
         return e ? atoi(e) : 40;
     }();
-    static const int a2b_dbg = [] {
-        const char* e = getenv("HPE_MESH_A2B_DBG");
-        return e ? atoi(e) : 0;
-    }();
     static const int a2b_slices = [] {
         const char* e = getenv("HPE_MESH_A2B_SLICES");  // workgroups per image of the grid search (0: about 512 / B)
         return e ? atoi(e) : 0;
@@ -924,7 +916,7 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
         nslice = std::max(1, std::min(nslice, m.nA));
         const int min_cells = a2b_min_cells * (64 / (cell * cell));  // the knob is in 8 x 8-pixel cells
         hipLaunchKernelGGL(a2b_grid_variants[a2b_variant].fn, dim3(nslice, B), dim3(1024), grid_lds, st, m.bits, m.counts, v2d, H, W, m.WW, P,
-                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, min_cells, a2b_dbg);
+                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, min_cells);
         hipError_t eg = hipGetLastError();
         if (eg != hipSuccess) return eg;
         hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk,

@@ -798,6 +798,49 @@ def test_val_losses_one_call_matches_per_stage_calls(engine, assets):
     assert (only_kp[:, 3] == 0).all()
 
 
+def test_full_size_losses_are_sums_over_images(assets):
+    """BASELINE configs[4] at the metric batch (256 images): the oracle's Python loop over 256 x P_i x 6890 distance matrices
+    is out of reach there, so check what the reference's definition gives for free -- both losses are sums over images
+    (src/ops.py:133-136 adds the per-image mesh terms; kp numerator and visible count are sums): the packed block of the full
+    batch equals the sum of the blocks of its four 64-image quarters, stage by stage, on the path's own outputs (the
+    stage-1 meshes take the cell-grid search, the collapsed stage-3 meshes the full search), and two single images
+    agree with the oracle."""
+    import torch
+
+    B = 256
+    eng = hpe_amd.HpeEngine(device=0, max_batch=B)
+    eng.load_smpl(assets["smpl"])
+    eng.load_encoder(assets["enc"])
+    eng.load_regressor(assets["reg"])
+    eng.load_mean_theta(assets["mean_var"])
+    eng.finalize()
+    img = torch.from_numpy(synthetic.make_images(B, seed=556)).cuda()
+    seg_np, kp_np = synthetic.make_lsp_targets(B, seed=557)
+    seg = torch.from_numpy(seg_np[..., 0].copy()).cuda()
+    kp_gt = torch.from_numpy(kp_np).cuda()
+    outs = eng.forward(img, all_stages=True, want=eng.DEFAULT_OUTPUTS + ("verts2d",))
+    full = cpu(eng.val_losses(kp_gt, [o["kp2d"] for o in outs], seg, [o["verts2d"] for o in outs])).astype(np.float64)
+    acc = np.zeros_like(full)
+    for q in range(4):
+        sl = slice(64 * q, 64 * q + 64)
+        part = cpu(eng.val_losses(kp_gt[sl].contiguous(), [o["kp2d"][sl].contiguous() for o in outs], seg[sl].contiguous(),
+                                  [o["verts2d"][sl].contiguous() for o in outs])).astype(np.float64)
+        acc[:, 0] += part[:, 0]
+        acc[:, 1] += part[:, 1]
+        acc[:, 3] += part[:, 3]
+    for st in range(3):
+        assert abs(full[st, 0] - acc[st, 0]) <= 1e-5 * abs(acc[st, 0]), (st, full[st], acc[st])
+        assert full[st, 1] == acc[st, 1]
+        assert abs(full[st, 3] - acc[st, 3]) <= 1e-5 * abs(acc[st, 3]), (st, full[st], acc[st])
+    for b in (0, B - 1):
+        for st in (0, 2):
+            v2d = cpu(outs[st]["verts2d"][b:b + 1])
+            ref = O.mesh_reprojection_loss(O.silhouette_points(seg_np[b:b + 1]), v2d, 1)
+            one = float(cpu(hpe_amd.mesh_reprojection_loss(eng, seg[b:b + 1].contiguous(), outs[st]["verts2d"][b:b + 1].contiguous())))
+            assert abs(one - ref) <= 1.5e-4 * abs(ref), (b, st, one, ref)
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------- asset ingestion from files (SURVEY §8(f) row 1)
 def test_predictor_from_files(tmp_path, assets):
     """Predictor(config) with nothing but paths, like the reference: SMPL model from a (chumpy-free) pickle with scipy-sparse
