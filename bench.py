@@ -405,9 +405,19 @@ def main():
                  "step_ms_events": round(tm["total_ms"], 3)}
         eng.enable_timing(0)
         if rank == 0 and os.environ.get("HPE_BENCH_LAYERS"):
-            for s, ms in zip(hpe_amd.resnet_spec.CONV_SPECS, per_conv):
-                fl = 2.0 * s.kh * s.kw * s.cin * s.cout * s.hout * s.hout * B
-                print("%-18s %8.3f ms %7.1f TF" % (s.name, ms, fl / ms / 1e9), file=sys.stderr)
+            specs = list(hpe_amd.resnet_spec.CONV_SPECS)
+            flops = {s.name: 2.0 * s.kh * s.kw * s.cin * s.cout * s.hout * s.hout * B for s in specs}
+            for s, ms in zip(specs, per_conv):
+                fl, note = flops[s.name], ""
+                # conv_block: the projection shortcut runs inside branch2c's launch (dual-source GEMM) and has no launch of its own
+                short = s.name.replace("branch2c", "branch1")
+                dual = os.environ.get("HPE_DUAL", "1") != "0" and s.name.endswith("a_branch2c") and short in flops
+                if dual:
+                    fl, note = fl + flops[short], "  (+ %s in the same launch)" % short
+                if s.name.endswith("branch1") and os.environ.get("HPE_DUAL", "1") != "0":
+                    print("%-18s %8.3f ms        -     (inside %s)" % (s.name, ms, s.name.replace("branch1", "branch2c")), file=sys.stderr)
+                    continue
+                print("%-18s %8.3f ms %7.1f TF%s" % (s.name, ms, fl / ms / 1e9, note), file=sys.stderr)
 
     # ---- steady state: the same step, untimed by the driver, for >= args.sustain seconds with power / clock sampled
     sustained = None
