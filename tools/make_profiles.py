@@ -44,8 +44,13 @@ def main():
             with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (name, tag)), "w") as f:
                 f.write(csv)
     for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "layers_*.txt")) + glob.glob(os.path.join(src, "power_trace_*.csv")) + \
-            glob.glob(os.path.join(src, "latency_small_batch.txt")):
+            glob.glob(os.path.join(src, "latency_small_batch.txt")) + glob.glob(os.path.join(src, "mesh_loss_search.txt")):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+    kt3 = os.path.join(src, "prof_fp32", "kt3", "kt3_results.db")
+    if os.path.isfile(kt3):
+        out = subprocess.run([sys.executable, os.path.join(HERE, "timeline_gaps.py"), kt3], capture_output=True, text=True, check=True).stdout
+        with open(os.path.join(dst, "timeline_fp32.txt"), "w") as f:
+            f.write("# tools/timeline_gaps.py on the default fp32 run (2 chunk streams + pipelined tail, B = 256) of tools/profile_step.sh\n" + out)
     print("\n".join(sorted(os.listdir(dst))))
 
 

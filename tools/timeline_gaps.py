@@ -1,7 +1,7 @@
 """GPU busy / idle time of the timed steps of a `rocprofv3 --kernel-trace` run of bench.py (rocpd sqlite database):
 union of the kernel intervals, idle gaps, mean number of kernels in flight, per stream when the table has one.
 
-    python tools/timeline_gaps.py <kt_results.db> [first_kernel_substring]
+    python tools/timeline_gaps.py <kt_results.db> [chunks_per_step [first_kernel_substring]]
 """
 import sqlite3
 import sys
@@ -9,17 +9,13 @@ import sys
 
 def main():
     db = sys.argv[1]
-    first = sys.argv[2] if len(sys.argv) > 2 else "stem_fused_"
+    per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # batch chunks per step (HPE_STREAMS)
+    first = sys.argv[3] if len(sys.argv) > 3 else "stem_fused_"
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, start, end from kernels order by start"))
     starts = [i for i, r in enumerate(rows) if first in r[0]]
-    # group launches of the first kernel that belong to one step (chunk streams launch it once per chunk, close together)
-    steps = []
-    for i in starts:
-        if not steps or rows[i][1] - rows[steps[-1][-1]][1] > 2_000_000:
-            steps.append([i])
-        else:
-            steps[-1].append(i)
+    # the first kernel is launched once per batch chunk: every `per_step`-th launch opens a step
+    steps = [starts[i:i + per_step] for i in range(0, len(starts) - per_step + 1, per_step)]
     if len(steps) < 3:
         raise SystemExit("need >= 3 steps in the trace")
     lo, hi = steps[1][0], steps[-1][0]  # from the 2nd step's first kernel to the last step's first kernel
