@@ -9,6 +9,10 @@ HPE_POWER_TRACE=$OUT/power_trace_bf16.csv python bench.py --steps 30 --warmup 5 
 python bench.py --steps 10 --warmup 3 --config5 --cpu-sample 0 2>/dev/null > $OUT/bench_config5.json
 HPE_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --sustain 0 2>/dev/null > $OUT/bench_fp32_rccl_world1.json
 HPE_STREAMS=1 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --sustain 0 2>/dev/null > $OUT/bench_fp32_streams1.json
+python bench.py --steps 20 --warmup 5 --cpu-sample 0 --sustain 0 --no-pipeline 2>/dev/null > $OUT/bench_fp32_no_pipeline.json
+python bench.py --steps 30 --warmup 5 --cpu-sample 0 --sustain 0 --no-pipeline --encoder-dtype bf16 2>/dev/null > $OUT/bench_bf16_no_pipeline.json
+HPE_FORCE_DIST=1 python bench.py --steps 30 --warmup 5 --cpu-sample 0 --sustain 0 --encoder-dtype bf16 2>/dev/null > $OUT/bench_bf16_rccl_world1.json
+HPE_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --sustain 0 --config5 2>/dev/null > $OUT/bench_config5_rccl_world1.json
 HPE_STEM_FUSED=0 HPE_DUAL=0 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --sustain 0 2>/dev/null > $OUT/bench_fp32_r1_structure.json
 HPE_STEM_FUSED=0 HPE_DUAL=0 HPE_BF16_RULES=0 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --sustain 0 --encoder-dtype bf16 2>/dev/null > $OUT/bench_bf16_r1_structure.json
 HPE_BENCH_LAYERS=1 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --sustain 0 2>$OUT/layers_fp32.txt > /dev/null

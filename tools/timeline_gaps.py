@@ -24,13 +24,14 @@ def main():
     n_steps = len(steps) - 2
     busy, cur_end, gaps = 0, t0, []
     for _n, s, e in seg:
+        e = min(e, t1)
         if s > cur_end:
             gaps.append(s - cur_end)
             cur_end = s
         if e > cur_end:
             busy += e - cur_end
             cur_end = e
-    total = sum(e - s for _n, s, e in seg)
+    total = sum(min(e, t1) - s for _n, s, e in seg)
     wall = t1 - t0
     print("steps %d  wall %.3f ms/step  busy (union) %.3f ms/step = %.1f %%  sum of kernel times %.3f ms/step (%.2f in flight)"
           % (n_steps, wall / n_steps / 1e6, busy / n_steps / 1e6, 100.0 * busy / wall, total / n_steps / 1e6, total / busy))
