@@ -496,6 +496,26 @@ def test_mesh_loss_degenerate_and_far(engine, assets):
     assert abs(out - ref) / abs(ref) < 1e-5, (out, ref)
 
 
+@pytest.mark.parametrize("H,W,P", [(75, 100, 333), (224, 224, 100), (61, 130, 6890), (8, 8, 5)])
+def test_mesh_loss_other_geometries(engine, H, W, P):
+    """hpe_mesh_loss takes any image size and vertex count: maps that are not multiples of the 8-pixel tiles / cells, vertex
+    counts that are not multiples of the 32-vertex chunks, a map with fewer cells than the grid search wants (-> full
+    search).  Vertices spread over (and a little beyond) the image; against the oracle and the exact fp64 search."""
+    g = np.random.Generator(np.random.Philox(1000 + H + P))
+    B = 3
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    seg = np.zeros((B, H, W, 1), np.float32)
+    for b in range(B):
+        seg[b, :, :, 0] = ((xx - W * (0.4 + 0.1 * b)) ** 2 / (0.3 * W) ** 2 + (yy - H * 0.5) ** 2 / (0.4 * H) ** 2 <= 1.0)
+    seg[2, :, :, 0] *= (np.arange(W)[None, :] % 2 == 0)
+    v = np.stack([g.uniform(-0.1 * W, 1.1 * W, (B, P)), g.uniform(-0.1 * H, 1.1 * H, (B, P))], -1).astype(np.float32)
+    out = float(cpu(hpe_amd.mesh_reprojection_loss(engine, gpu(seg), gpu(v))))
+    ref = float(O.mesh_reprojection_loss(O.silhouette_points(seg), v, B))
+    exact = sum(_mesh_loss_fp64(seg[b, :, :, 0], v[b]) for b in range(B))
+    assert abs(out - exact) <= 1.5e-4 * abs(exact), (out, exact)
+    assert abs(ref - exact) <= 1.5e-4 * abs(exact), (ref, exact)
+
+
 def test_mesh_loss(engine, assets):
     B = 2
     seg, _ = synthetic.make_lsp_targets(B, seed=14)
