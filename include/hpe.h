@@ -149,7 +149,11 @@ int hpe_reproject_vertices(const float* verts_dev, const float* cam_dev, int B, 
  * Numerator and count are returned separately so that ranks can all-reduce them before dividing. */
 int hpe_kp_loss(const float* kp_gt_dev, const float* kp_pred_dev, int B, int K, float* out_dev, void* stream);
 /* mesh_reprojection_loss (src/ops.py:117-137) forward: seg_dev [B,H,W] (>0 = silhouette), verts2d_dev
- * [B,P,2] pixels -> out_dev[0] = sum_i bidirectional_dist_i / (3 + P).  workspace from the ctx. */
+ * [B,P,2] pixels -> out_dev[0] = sum_i bidirectional_dist_i / (3 + P).  workspace from the ctx.
+ * Nearest neighbours (find_nearest_neighbors, src/ops.py:60-71) are exact: the argmin of the expanded squared distance
+ * -2 a.b + |a|^2 + |b|^2 evaluated in fp32, ties to the lowest index as tf.argmin; any H, W, P (the pixel -> vertex search
+ * prunes by a cell grid over the vertices when they fit its LDS image, else -- and for meshes concentrated in a few cells --
+ * it evaluates every pair; the two give the same neighbours). */
 int hpe_mesh_loss(hpe_ctx* ctx, const float* seg_dev, const float* verts2d_dev, int B, int H, int W, int P, float* out_dev,
                   void* stream);
 
