@@ -121,6 +121,8 @@ constexpr size_t WINO_V_SLACK = 524288;
 // tile-selection overrides (HPE_TILE_WIDE / HPE_TILE_NARROW / HPE_SHORTK_TILE / HPE_TILE_BF16), read once in hpe_finalize
 struct TileKnobs {
     int force_wide = -1, force_narrow = -1, shortk = TILE_128x64_W8, force_bf16 = -1;
+    int bf16_128_min_tiles = 192;  // HPE_BF16_128_MIN_TILES: concurrent chunk launches take 128x128 from 0.75 tiles per CU on
+    int wide128_min_tiles = 384;  // HPE_WIDE128_MIN_TILES: 1.5 tiles per CU (0 = the round-1 rule everywhere)
     int force_expand = -1;   // HPE_EXPAND_TILE: fp32 tile of the identity-block expand layers (experiment knob)
     int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
     int bf16_rules = 1;      // HPE_BF16_RULES=0: the round-1 tile rule (128x128 / 64x128 by grid size, double buffer)
@@ -224,7 +226,7 @@ int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
     return HPE_OK;
 }
 
-int pick_tile(const TileKnobs& kn, int M, int N, int K, bool residual_expand = false) {
+int pick_tile(const TileKnobs& kn, int M, int N, int K, bool residual_expand = false, bool concurrent = false) {
     // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
     const bool wide = N > 64;
     if (wide && residual_expand) return kn.force_expand >= 0 ? kn.force_expand : TILE_128x64_W8;
@@ -238,6 +240,11 @@ int pick_tile(const TileKnobs& kn, int M, int N, int K, bool residual_expand = f
     // (profiles/r01/h_tile_128x64w8.txt: res2*_branch2c 0.41-0.43 -> 0.37-0.38 ms, res3*_branch2c 0.31 -> 0.28 ms; stages 4-5:
     // equal to the 64x64 tile within 1 %, profiles/r02/fp32_expand_tile.txt)
     if (K <= 128 && M >= 150000) return kn.shortk;
+    // Launches of concurrent batch chunks: 128x128 wherever it still leaves >= 1.5 tiles per CU (round 2, pipelined steps + two chunk
+    // streams at B = 256: 17,440 -> 17,830 img/s, B = 128: +0.7 %, although most of these layers are 5-10 % SLOWER with it when they
+    // run alone -- fewer, longer workgroups leave the co-running chunk's kernels more room).  A single-chunk batch keeps the
+    // round-1 rule (B = 64: -0.6 ... -1.2 % with 128x128).  Thresholds 300 / 390 / 700 tiles: 17,805 / 17,843 / 17,806 img/s.
+    if (concurrent && kn.wide128_min_tiles > 0 && (long)((M + 127) / 128) * ((N + 127) / 128) >= kn.wide128_min_tiles) return TILE_128x128;
     if (M >= 150000) return TILE_64x128;
     return TILE_64x64;
 }
@@ -251,11 +258,11 @@ struct Bf16Plan {
 //    and residual loads (res2b_branch2c 0.273 -> 0.182 ms = 5.1 TB/s, res3* 0.157 -> 0.108, res4* 0.079 -> 0.062, res5* 0.061 -> 0.048)
 //  * everything with a long k axis on the small maps (stage 5: M = 49 B): 256x128, 8 waves (res5*_branch2b 0.112 -> 0.083 ms)
 //  * otherwise 128x128 while that still gives >= 512 workgroups, else 64x128
-Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expand) {
+Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expand, bool concurrent = false) {
     Bf16Plan pl{TILE_128x64, 2};
     if (N > 64) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        pl.tile = t128 >= 512 ? TILE_128x128 : TILE_64x128;
+        pl.tile = t128 >= (concurrent ? kn.bf16_128_min_tiles : 512) ? TILE_128x128 : TILE_64x128;
         if (kn.bf16_rules) {
             if (residual_expand) pl.tile = TILE_128x64_W8;
             else if (M <= 16384 && M >= 8192 && K >= 1024 && N >= 256) pl.tile = TILE_256x128_W8;
@@ -350,10 +357,10 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     }
     if (c->bf16) {
         p.cin_slabs = s.cin / 64;
-        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin);
+        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin, (flags & CONV_CONCURRENT) != 0);
         return hpe_launch_gemm_bf16(p, mode, pl.tile, pl.ns, st);
     }
-    return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin), st);
+    return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin, (flags & CONV_CONCURRENT) != 0), st);
 }
 
 // branch2c (+BN) + branch1 (+BN) + add + ReLU of a conv_block as one dual-source GEMM: t2 [M, K1] dense, x NHWC strided
@@ -388,10 +395,10 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
         p.partial_floats = c->partial_floats;
     }
     if (c->bf16) {
-        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, false);
+        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, false, (flags & CONV_CONCURRENT) != 0);
         return hpe_launch_gemm_bf16(p, GEMM_DUAL, pl.tile, pl.ns, st);
     }
-    return hpe_launch_gemm(p, GEMM_DUAL, pick_tile(c->knobs, p.M, p.N, p.K), st);
+    return hpe_launch_gemm(p, GEMM_DUAL, pick_tile(c->knobs, p.M, p.N, p.K, false, (flags & CONV_CONCURRENT) != 0), st);
 }
 
 hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
@@ -757,6 +764,10 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_fused = (e ? atoi(e) : 1) && c->wino_min_c > 0;
         e = getenv("HPE_WINO_FUSED_MINHW");
         c->wino_fused_min_hw = e ? atoi(e) : 28;
+        e = getenv("HPE_BF16_128_MIN_TILES");
+        if (e) c->knobs.bf16_128_min_tiles = atoi(e);
+        e = getenv("HPE_WIDE128_MIN_TILES");
+        if (e) c->knobs.wide128_min_tiles = atoi(e);
         e = getenv("HPE_TILE_WIDE");
         c->knobs.force_wide = e ? atoi(e) : -1;
         e = getenv("HPE_TILE_NARROW");
