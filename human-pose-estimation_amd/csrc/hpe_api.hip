@@ -122,6 +122,7 @@ constexpr size_t WINO_V_SLACK = 524288;
 struct TileKnobs {
     int force_wide = -1, force_narrow = -1, shortk = TILE_128x64_W8, force_bf16 = -1;
     int bf16_128_min_tiles = 192;  // HPE_BF16_128_MIN_TILES: concurrent chunk launches take 128x128 from 0.75 tiles per CU on
+    int concurrent_tiles = 0;      // HPE_CONCURRENT_TILES=1: the tile rule of concurrent chunk launches on every launch (profiling passes with HPE_STREAMS=1)
     int wide128_min_tiles = 384;  // HPE_WIDE128_MIN_TILES: 1.5 tiles per CU (0 = the round-1 rule everywhere)
     int force_expand = -1;   // HPE_EXPAND_TILE: fp32 tile of the identity-block expand layers (experiment knob)
     int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
@@ -244,7 +245,7 @@ int pick_tile(const TileKnobs& kn, int M, int N, int K, bool residual_expand = f
     // streams at B = 256: 17,440 -> 17,830 img/s, B = 128: +0.7 %, although most of these layers are 5-10 % SLOWER with it when they
     // run alone -- fewer, longer workgroups leave the co-running chunk's kernels more room).  A single-chunk batch keeps the
     // round-1 rule (B = 64: -0.6 ... -1.2 % with 128x128).  Thresholds 300 / 390 / 700 tiles: 17,805 / 17,843 / 17,806 img/s.
-    if (concurrent && kn.wide128_min_tiles > 0 && (long)((M + 127) / 128) * ((N + 127) / 128) >= kn.wide128_min_tiles) return TILE_128x128;
+    if ((concurrent || kn.concurrent_tiles) && kn.wide128_min_tiles > 0 && (long)((M + 127) / 128) * ((N + 127) / 128) >= kn.wide128_min_tiles) return TILE_128x128;
     if (M >= 150000) return TILE_64x128;
     return TILE_64x64;
 }
@@ -262,7 +263,7 @@ Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expan
     Bf16Plan pl{TILE_128x64, 2};
     if (N > 64) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        pl.tile = t128 >= (concurrent ? kn.bf16_128_min_tiles : 512) ? TILE_128x128 : TILE_64x128;
+        pl.tile = t128 >= ((concurrent || kn.concurrent_tiles) ? kn.bf16_128_min_tiles : 512) ? TILE_128x128 : TILE_64x128;
         if (kn.bf16_rules) {
             if (residual_expand) pl.tile = TILE_128x64_W8;
             else if (M <= 16384 && M >= 8192 && K >= 1024 && N >= 256) pl.tile = TILE_256x128_W8;
@@ -764,6 +765,8 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_fused = (e ? atoi(e) : 1) && c->wino_min_c > 0;
         e = getenv("HPE_WINO_FUSED_MINHW");
         c->wino_fused_min_hw = e ? atoi(e) : 28;
+        e = getenv("HPE_CONCURRENT_TILES");
+        c->knobs.concurrent_tiles = e ? atoi(e) : 0;
         e = getenv("HPE_BF16_128_MIN_TILES");
         if (e) c->knobs.bf16_128_min_tiles = atoi(e);
         e = getenv("HPE_WIDE128_MIN_TILES");
