@@ -496,11 +496,11 @@ def test_mesh_loss_degenerate_and_far(engine, assets):
     assert abs(out - ref) / abs(ref) < 1e-5, (out, ref)
 
 
-@pytest.mark.parametrize("H,W,P", [(75, 100, 333), (224, 224, 100), (61, 130, 6890), (8, 8, 5)])
+@pytest.mark.parametrize("H,W,P", [(75, 100, 333), (224, 224, 100), (61, 130, 6890), (8, 8, 5), (224, 224, 12000), (40, 600, 2000)])
 def test_mesh_loss_other_geometries(engine, H, W, P):
     """hpe_mesh_loss takes any image size and vertex count: maps that are not multiples of the 8-pixel tiles / cells, vertex
-    counts that are not multiples of the 32-vertex chunks, a map with fewer cells than the grid search wants (-> full
-    search).  Vertices spread over (and a little beyond) the image; against the oracle and the exact fp64 search."""
+    counts that are not multiples of the 32-vertex chunks, a map with fewer cells than the grid search wants, more vertices than its LDS image
+    holds, a map wider than the bitmap path takes (-> full search / point-list B -> A search).  Vertices spread over (and a little beyond) the image; against the oracle and the exact fp64 search."""
     g = np.random.Generator(np.random.Philox(1000 + H + P))
     B = 3
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
