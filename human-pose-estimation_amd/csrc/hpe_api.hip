@@ -176,6 +176,7 @@ struct hpe_ctx {
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
+    int min_chunk = 44;  // HPE_MIN_CHUNK: smallest batch chunk that still gets its own stream
     hipEvent_t ev_fork{}, ev_join[3]{};
     // software pipeline across calls (hpe_forward_pipelined): the regressor + SMPL tail of batch k runs on `tail_st` while the
     // caller's stream already runs the encoder of batch k+1; features alternate between two buffers, the Dense layers of the tail
@@ -516,16 +517,17 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
 // back-to-back launches on one stream and therefore runs unchunked.
 hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
     int nstream = c->n_streams;
-    // a chunk needs >= 64 images to keep its own launches efficient (measured: B = 64 is 7 % faster unchunked, B = 128 best
-    // with 2 chunks, B = 256 equal for 2-4; profiles/r01/g_wino_chunk_rule.txt)
-    if (nstream > B / 64) nstream = B / 64;
+    // a chunk needs >= 44 images to keep its own launches efficient (round 1: B = 64 is 7 % faster unchunked, B = 128 best with 2
+    // chunks, B = 256 equal for 2-4, profiles/r01/g_wino_chunk_rule.txt; round 2: B = 72 / 80 unchunked 15.1 / 15.2 k img/s against
+    // 14.6 k in two chunks, B = 88 / 96 / 112 in two chunks 15.3 / 15.4 / 15.6 k against 14.3 / 14.8 / 15.3 k unchunked)
+    if (nstream > B / c->min_chunk) nstream = B / c->min_chunk;
     if (c->timing >= 2 || nstream < 2) nstream = 1;
     if (nstream == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
-    // chunk size: about HPE_CHUNK images (default: one chunk per stream), never below 64 -- smaller chunks are launch bound
+    // chunk size: about HPE_CHUNK images (default: one chunk per stream), never below min_chunk -- smaller chunks are launch bound
     //  -- and all chunks of equal size +-1; chunks go round-robin over the streams
     int nchunk = nstream;
     if (c->chunk_images > 0) {
-        const int want = c->chunk_images < 64 ? 64 : c->chunk_images;
+        const int want = c->chunk_images < c->min_chunk ? c->min_chunk : c->chunk_images;
         nchunk = B / want;
         if (nchunk < nstream) nchunk = nstream;
     }
@@ -1074,6 +1076,8 @@ static int finalize_impl(hpe_ctx* c) {
         if (ns < 1) ns = 1;
         if (ns > 4) ns = 4;
         c->n_streams = ns;
+        e = getenv("HPE_MIN_CHUNK");
+        if (e && atoi(e) >= 8) c->min_chunk = atoi(e);
         e = getenv("HPE_CHUNK");
         c->chunk_images = e ? atoi(e) : 0;
         for (int i = 0; i < ns - 1; ++i) HIP_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));

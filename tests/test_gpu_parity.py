@@ -372,12 +372,13 @@ def test_encoder_features(engine, assets):
     assert rel(f, ref32) < 2e-5
 
 
-@pytest.mark.parametrize("B", [7, 26])
+@pytest.mark.parametrize("B", [7, 26, 90])
 def test_encoder_features_mid_batches(assets, B):
     """Batches between the single-frame and the full-size cases: the fused stem switches strip height with the batch (B = 7: 2
     pooled rows per workgroup, B = 26: 4), the Winograd / direct and split-K decisions change per layer, pixel counts are not
-    multiples of the GEMM tiles.  Two images of each batch against the oracle, all of them against a batch-of-2 run."""
-    e = _engine_with_env(assets, {}, 32)
+    multiples of the GEMM tiles; B = 90 is the smallest kind of batch that runs as two concurrent chunks (45 images each).
+    Two images of each batch against the oracle, all of them against a batch-of-2 run."""
+    e = _engine_with_env(assets, {}, max(32, B))
     img = synthetic.make_images(B, seed=120 + B)
     f = cpu(e.encoder(gpu(img)))
     pick = [0, B - 1]
@@ -766,7 +767,7 @@ def _engine_with_env(assets, env, max_batch, encoder_only=True, **kw):
 
 def test_chunk_knob_is_clamped_and_race_free(assets):
     """HPE_CHUNK below 64 used to let 16-image chunks on 3 streams share the single split-K workspace: the
-    knob is now clamped to >= 64 images per chunk and chunked launches never split K.  B = 130 with HPE_CHUNK=16 must
+    knob is now clamped to >= 44 images per chunk (HPE_MIN_CHUNK) and chunked launches never split K.  B = 130 with HPE_CHUNK=16 must
     reproduce the unchunked (HPE_STREAMS=1) features bit for bit over repeated runs -- both take whole-tile launches."""
     img = gpu(synthetic.make_images(130, seed=98))
     base = _engine_with_env(assets, {"HPE_STREAMS": "1"}, 130)
