@@ -801,6 +801,26 @@ def test_bf16_full_size_batch_invariance(assets):
     eng.close()
 
 
+def test_bf16_mid_batch_two_chunks(assets):
+    """bf16 encoder at B = 50: the smallest kind of bf16 batch that runs as two concurrent chunks (25 images each; pixel counts
+    that are no multiples of the tiles, 128x128 tiles where a chunk still has enough of them): rows against the same images in
+    a batch of 3 and against the bf16 emulation of the oracle."""
+    import torch
+
+    eng = _engine_with_env(assets, {}, 64, encoder_dtype="bf16")
+    img = torch.from_numpy(synthetic.make_images(50, seed=557)).cuda()
+    pick = [0, 24, 25, 49]
+    fb = cpu(eng.encoder(img))[pick]
+    fs = cpu(eng.encoder(img[pick].contiguous()))
+    l2 = float(np.linalg.norm(fb - fs) / np.linalg.norm(fs))
+    assert l2 < 1e-3, l2
+    ref = O.resnet50_features(cpu(img[pick[:2]]), assets["enc"], act_round="bf16", bf16_folded=BF16_FOLDED)
+    l2r = float(np.linalg.norm(fb[:2] - ref) / np.linalg.norm(ref))
+    print("bf16 features, B=50 (2 chunks) vs emulation: rel-L2 %.3g" % l2r)
+    assert l2r < 3e-3, l2r
+    eng.close()
+
+
 def test_val_losses_one_call_matches_per_stage_calls(engine, assets):
     """hpe_val_losses (silhouette work hoisted out of the stages) against the per-stage entry points, bit for bit."""
     B = 3
