@@ -18,7 +18,7 @@ except ValueError:
 from . import resnet_spec, synthetic  # noqa: F401,E402
 from ._lib import HpeError  # noqa: F401
 from .engine import HpeEngine  # noqa: F401
-from .image import get_original, preprocess_image  # noqa: F401
+from .image import get_original, preprocess_batch, preprocess_image  # noqa: F401
 from .ops import kp_reprojection_loss, mesh_reprojection_loss  # noqa: F401
 from .predictor import Predictor  # noqa: F401
 from .projection import batch_orth_proj_idrot, reproject_vertices  # noqa: F401

@@ -30,7 +30,20 @@ class HpeConfig(C.Structure):
         ("num_stage", C.c_int),
         ("bn_eps", C.c_float),
         ("encoder_dtype", C.c_int),
+        # plan options (-1 = default: environment variable, else built-in); see include/hpe.h
+        ("n_streams", C.c_int),
+        ("dual_gemm", C.c_int),
+        ("stem_fused", C.c_int),
+        ("wino_min_c", C.c_int),
+        ("wino_min_items", C.c_int),
+        ("wino_fused", C.c_int),
+        ("wino_fused_min_hw", C.c_int),
+        ("mesh_a2b", C.c_int),
+        ("wino_f4", C.c_int),
     ]
+
+
+PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4")
 
 
 class HpeSmplModel(C.Structure):
@@ -59,6 +72,7 @@ _PROTOS = {
     "hpe_conv_layer_name": (C.c_char_p, [C.c_int]),
     "hpe_bn_layer_name": (C.c_char_p, [C.c_int]),
     "hpe_conv_layer_geometry": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "hpe_config_init": (None, [C.POINTER(HpeConfig)]),
     "hpe_create": (C.c_int, [C.POINTER(HpeConfig), C.POINTER(C.c_void_p)]),
     "hpe_destroy": (C.c_int, [C.c_void_p]),
     "hpe_load_smpl": (C.c_int, [C.c_void_p, C.POINTER(HpeSmplModel)]),
@@ -69,6 +83,7 @@ _PROTOS = {
     "hpe_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(HpeOutputs), C.c_int, C.c_void_p]),
     "hpe_forward_pipelined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(HpeOutputs), C.c_int, C.c_void_p]),
     "hpe_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hpe_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(HpeOutputs), C.c_int, C.c_void_p]),
     "hpe_tail_stream": (C.c_void_p, [C.c_void_p]),
     "hpe_encoder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_regress_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -76,6 +91,8 @@ _PROTOS = {
     "hpe_orth_proj": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_reproject_vertices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "hpe_preprocess_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "hpe_preprocess_u8_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                          C.c_void_p, C.c_void_p]),
     "hpe_get_original": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpe_kp_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_mesh_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -91,7 +108,9 @@ _PROTOS = {
     "hpe_debug_joint_regress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "hpe_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "hpe_get_span_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "hpe_get_loss_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "hpe_debug_set_loss_counter": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpe_get_conv_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }
 

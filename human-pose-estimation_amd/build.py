@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpe_hip.so")
 SOURCES = ["conv_gemm.hip", "conv_gemm_bf16.hip", "conv_wino.hip", "stem_fused.hip", "encoder_ops.hip", "smpl.hip", "losses.hip", "prepost.hip", "hpe_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fno-fast-math"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-fast-math"]
 
 
 def _hipcc():
@@ -24,6 +24,17 @@ def _hipcc():
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "hpe.h")]
+
+
+def _obj_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + _deps() if os.path.exists(d))
 
 
 def _stale():
@@ -35,19 +46,53 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source into lib/libhpe_hip.so.  Returns the library path."""
+    """Compile every HIP source (one object per file, in parallel; only the stale ones) and link lib/libhpe_hip.so.
+    Returns the library path."""
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    tmp = LIB + ".tmp%d" % os.getpid()
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
     extra = os.environ.get("HPE_EXTRA_FLAGS", "").split()
-    cmd = [_hipcc()] + FLAGS + extra + ["-o", tmp] + srcs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+    tag = os.path.join(objdir, "flags.txt")
+    flags_now = " ".join(CFLAGS + extra)
+    if force or not os.path.exists(tag) or open(tag).read() != flags_now:
+        for f in os.listdir(objdir):
+            os.remove(os.path.join(objdir, f))
+    hipcc = _hipcc()
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        if not _obj_stale(src, obj):
+            return None
+        cmd = [hipcc] + CFLAGS + extra + ["-c", "-o", obj + ".tmp%d" % os.getpid(), src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            return "hipcc failed on %s:\n%s%s" % (os.path.basename(src), r.stdout, r.stderr)
+        os.replace(obj + ".tmp%d" % os.getpid(), obj)
+        return None
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
+        errs = [e for e in ex.map(compile_one, jobs) if e]
+    if errs:
+        raise RuntimeError("\n".join(errs))
+    open(tag, "w").write(flags_now)
+    tmp = LIB + ".tmp%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [o for _, o in jobs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(tmp, LIB)
     return LIB
 

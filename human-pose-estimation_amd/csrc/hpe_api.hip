@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -174,6 +175,9 @@ struct hpe_ctx {
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
+    int mesh_a2b = 0;         // pixel -> vertex search of the mesh loss: 0 cell grid, 1 VALU full search, 2 matrix-core full search
+    bool loss_attr_done = false;  // per-device kernel attributes of the loss kernels set (hpe_finalize, or the first loss call of a loss-only ctx)
+    unsigned long long* loss_counter = nullptr;  // hpe_debug_set_loss_counter
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
     int min_chunk = 44;  // HPE_MIN_CHUNK: smallest batch chunk that still gets its own stream
@@ -193,6 +197,10 @@ struct hpe_ctx {
     // timing
     int timing = 0;
     hipEvent_t ev[8]{};
+    // encoder span of every timed call since hpe_enable_timing (ring of the last SPAN_RING calls): hpe_get_span_stats
+    static constexpr int SPAN_RING = 64;
+    hipEvent_t span0[SPAN_RING]{}, span1[SPAN_RING]{};
+    unsigned span_n = 0;
     hipEvent_t cev0[HPE_NUM_CONV]{}, cev1[HPE_NUM_CONV]{};
     hipEvent_t lev0[16]{}, lev1[16]{}, lev_all[2]{};  // hpe_val_losses: around each stage's pixel -> vertex search / the whole call
     int loss_timed_stages = 0;
@@ -457,7 +465,9 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
     float* nxt = at(c->X1, o_big);
     // the chunk's slice of the Winograd workspace (chunks of < 32 images only occur unchunked, i0 == 0: the slack at the end covers them)
     float* wv = (c->wino_v && (i0 == 0 || B >= 32)) ? c->wino_v + (size_t)i0 * WINO_V_PITCH : nullptr;
-    if (c->stem_fused) {
+    // the fused stem stages whole 16-byte chunks of the caller's rows; an images pointer that is only float-aligned (e.g. a
+    // tensor view at an odd offset) takes the pad / im2col / pool path, which reads the images with scalar loads
+    if (c->stem_fused && (reinterpret_cast<uintptr_t>(images + o_img) & 15) == 0) {
         // conv1_pad .. pool1 in one kernel straight from the caller's images (stem_fused.hip); timed as conv layer 0
         const bool t2 = c->timing >= 2;
         if (t2) HIPE(hipEventRecord(c->cev0[0], st));
@@ -600,8 +610,21 @@ int hpe_conv_layer_geometry(int idx, int out[7]) {
     return HPE_OK;
 }
 
+void hpe_config_init(HpeConfig* cfg) {
+    if (!cfg) return;
+    cfg->device = 0;
+    cfg->max_batch = 8;
+    cfg->num_stage = 3;
+    cfg->bn_eps = 1e-3f;
+    cfg->encoder_dtype = 0;
+    cfg->n_streams = cfg->dual_gemm = cfg->stem_fused = cfg->wino_min_c = cfg->wino_min_items = cfg->wino_fused = -1;
+    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = -1;
+}
+
 int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
     if (!cfg || !out) return fail(HPE_ERR_INVALID, "null argument");
+    if (cfg->n_streams > 4 || cfg->n_streams == 0) return fail(HPE_ERR_INVALID, "n_streams must be -1 (default) or 1..4");
+    if (cfg->mesh_a2b > 2) return fail(HPE_ERR_INVALID, "mesh_a2b must be -1 (default), 0 (grid), 1 (valu) or 2 (mfma)");
     if (cfg->max_batch < 1 || cfg->max_batch > 1024) return fail(HPE_ERR_INVALID, "max_batch must be in [1,1024]");
     if (cfg->num_stage < 1 || cfg->num_stage > 16) return fail(HPE_ERR_INVALID, "num_stage must be in [1,16]");
     if (cfg->encoder_dtype != 0 && cfg->encoder_dtype != 1) return fail(HPE_ERR_INVALID, "encoder_dtype must be 0 (fp32) or 1 (bf16)");
@@ -714,6 +737,8 @@ static void release_device_state(hpe_ctx* c) {
     }
     for (auto& e : c->ev_join) kill(e);
     for (auto& e : c->ev) kill(e);
+    for (auto& e : c->span0) kill(e);
+    for (auto& e : c->span1) kill(e);
     for (auto& e : c->cev0) kill(e);
     for (auto& e : c->cev1) kill(e);
     for (auto& e : c->lev0) kill(e);
@@ -759,14 +784,19 @@ static int finalize_impl(hpe_ctx* c) {
     DeviceGuard g(c->cfg.device);
     int rc;
     {
-        const char* e = getenv("HPE_WINO_MINC");  // 0 disables the Winograd path
-        c->wino_min_c = e ? atoi(e) : 128;
-        e = getenv("HPE_WINO_MIN_ITEMS");
-        c->wino_min_items = e ? atoi(e) : 128;
-        e = getenv("HPE_WINO_FUSED");
-        c->wino_fused = (e ? atoi(e) : 1) && c->wino_min_c > 0;
-        e = getenv("HPE_WINO_FUSED_MINHW");
-        c->wino_fused_min_hw = e ? atoi(e) : 28;
+        // plan options: HpeConfig field if >= 0, else the environment variable, else the built-in default
+        auto opt = [](int cfg_val, const char* env, int dflt) {
+            if (cfg_val >= 0) return cfg_val;
+            const char* v = getenv(env);
+            return v ? atoi(v) : dflt;
+        };
+        c->wino_min_c = opt(c->cfg.wino_min_c, "HPE_WINO_MINC", 128);  // 0 disables the Winograd path
+        c->wino_min_items = opt(c->cfg.wino_min_items, "HPE_WINO_MIN_ITEMS", 128);
+        c->wino_fused = opt(c->cfg.wino_fused, "HPE_WINO_FUSED", 1) && c->wino_min_c > 0;
+        c->wino_fused_min_hw = opt(c->cfg.wino_fused_min_hw, "HPE_WINO_FUSED_MINHW", 28);
+        c->stem_fused = opt(c->cfg.stem_fused, "HPE_STEM_FUSED", 1);
+        c->dual_gemm = opt(c->cfg.dual_gemm, "HPE_DUAL", 1);
+        const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
         c->knobs.concurrent_tiles = e ? atoi(e) : 0;
         e = getenv("HPE_BF16_128_MIN_TILES");
@@ -781,10 +811,6 @@ static int finalize_impl(hpe_ctx* c) {
         c->knobs.shortk = e ? atoi(e) : TILE_128x64_W8;
         e = getenv("HPE_TILE_BF16");
         c->knobs.force_bf16 = e ? atoi(e) : -1;
-        e = getenv("HPE_STEM_FUSED");
-        c->stem_fused = e ? atoi(e) : 1;
-        e = getenv("HPE_DUAL");
-        c->dual_gemm = e ? atoi(e) : 1;
         e = getenv("HPE_EXPAND_TILE");
         c->knobs.force_expand = e ? atoi(e) : -1;
         e = getenv("HPE_NS_BF16");
@@ -795,6 +821,8 @@ static int finalize_impl(hpe_ctx* c) {
         HIP_TRY(hpe_wino_init_device());
         HIP_TRY(hpe_stem_fused_init_device());
         HIP_TRY(hpe_losses_init_device());
+        c->mesh_a2b = c->cfg.mesh_a2b >= 0 ? c->cfg.mesh_a2b : hpe_mesh_a2b_mode_from_env();
+        c->loss_attr_done = true;
     }
     // ---- conv_block (first block of a stage): out = relu(bn2c(W2c . t2) + bn1(W1 . x_strided)).  Both convolutions are 1x1,
     //      so they are ONE GEMM over the concatenated k axis once each BN scale is folded into its weights:
@@ -1072,7 +1100,7 @@ static int finalize_impl(hpe_ctx* c) {
         // group alive 3 chunk streams cost 6 % in fp32 and 24 % in bf16 (profiles/r02/streams_vs_rccl.txt) -- while 2 and 3 chunk
         // streams are equal without one (17,306 vs 17,337 img/s).
         const char* e = getenv("HPE_STREAMS");
-        int ns = e ? atoi(e) : 2;
+        int ns = c->cfg.n_streams > 0 ? c->cfg.n_streams : (e ? atoi(e) : 2);
         if (ns < 1) ns = 1;
         if (ns > 4) ns = 4;
         c->n_streams = ns;
@@ -1092,6 +1120,8 @@ static int finalize_impl(hpe_ctx* c) {
         for (auto& ev : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->span0) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->span1) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->cev0) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->cev1) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->lev0) HIP_TRY(hipEventCreate(&e));
@@ -1109,9 +1139,14 @@ int hpe_encoder(hpe_ctx* c, const float* images, int B, float* features, void* s
     if (!images || !features) return fail(HPE_ERR_INVALID, "null pointer");
     DeviceGuard g(c->cfg.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[0], st));
+        HIP_TRY(hipEventRecord(c->span0[c->span_n % hpe_ctx::SPAN_RING], st));
+    }
     HIP_TRY(encoder_impl(c, images, B, features, HPE_FEATURE_DIM, st));
     if (c->timing) {
+        HIP_TRY(hipEventRecord(c->span1[c->span_n % hpe_ctx::SPAN_RING], st));
+        ++c->span_n;
         HIP_TRY(hipEventRecord(c->ev[1], st));
         HIP_TRY(hipEventRecord(c->ev[4], st));
         c->timed_valid = true;
@@ -1153,6 +1188,25 @@ int hpe_smpl(hpe_ctx* c, const float* theta, int B, const HpeOutputs* outs, void
     return HPE_OK;
 }
 
+// features [B,2048] -> feature projection (hoisted W1 block), then num_stage x (regressor step, SMPL of the stages that are returned);
+// feat_free (optional) is recorded once the features have been consumed
+static hipError_t tail_impl(hpe_ctx* c, const float* feat, int B, const HpeOutputs* stage_outs, int n_outs, hipStream_t ts, hipEvent_t feat_free) {
+    hipError_t e = features_proj(c, feat, B, ts);
+    if (e == hipSuccess && feat_free) e = hipEventRecord(feat_free, ts);
+    if (e == hipSuccess) e = hpe_launch_tile_theta(c->mean_dev, c->thA, B, THETA_LD, ts);
+    float* prev = c->thA;
+    float* next = c->thB;
+    const int first_out = c->cfg.num_stage - n_outs;
+    for (int s = 0; e == hipSuccess && s < c->cfg.num_stage; ++s) {
+        e = regress_impl(c, prev, next, B, ts);
+        if (e == hipSuccess && s >= first_out) e = hpe_launch_smpl(c->smpl, c->work, next, THETA_LD, B, &stage_outs[s - first_out], ts);
+        float* t = prev;
+        prev = next;
+        next = t;
+    }
+    return e;
+}
+
 // encoder on `st`; regressor + SMPL stages on `st` (pipelined == false) or on the ctx's tail stream behind an event (true)
 static int forward_impl(hpe_ctx* c, const float* images, int B, const HpeOutputs* stage_outs, int n_outs, hipStream_t st, bool pipelined) {
     int rc = check_ready(c, B, NEED_ENC | NEED_REG | NEED_SMPL);
@@ -1176,31 +1230,28 @@ static int forward_impl(hpe_ctx* c, const float* images, int B, const HpeOutputs
         HIP_TRY(hipStreamWaitEvent(st, c->ev_tail, 0));
         c->tail_pending = false;
     }
-    if (tm) HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (tm) {
+        HIP_TRY(hipEventRecord(c->ev[0], st));
+        HIP_TRY(hipEventRecord(c->span0[c->span_n % hpe_ctx::SPAN_RING], st));
+    }
     HIP_TRY(encoder_impl(c, images, B, feat, HPE_FEATURE_DIM, st));
-    if (tm) HIP_TRY(hipEventRecord(c->ev[1], st));
+    if (tm) {
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        HIP_TRY(hipEventRecord(c->span1[c->span_n % hpe_ctx::SPAN_RING], st));
+        ++c->span_n;
+    }
     if (pipelined) {
         HIP_TRY(hipEventRecord(c->ev_enc, st));
         HIP_TRY(hipStreamWaitEvent(ts, c->ev_enc, 0));
         c->dense_on_tail = true;
     }
-    hipError_t e = features_proj(c, feat, B, ts);
-    if (e == hipSuccess && pipelined) {
+    hipEvent_t feat_free = nullptr;
+    if (pipelined) {
         const unsigned slot = c->pipe_idx & 1u;
-        e = hipEventRecord(c->ev_feat_free[slot], ts);
+        feat_free = c->ev_feat_free[slot];
         c->feat_free_valid[slot] = true;
     }
-    if (e == hipSuccess) e = hpe_launch_tile_theta(c->mean_dev, c->thA, B, THETA_LD, ts);
-    float* prev = c->thA;
-    float* next = c->thB;
-    const int first_out = c->cfg.num_stage - n_outs;
-    for (int s = 0; e == hipSuccess && s < c->cfg.num_stage; ++s) {
-        e = regress_impl(c, prev, next, B, ts);
-        if (e == hipSuccess && s >= first_out) e = hpe_launch_smpl(c->smpl, c->work, next, THETA_LD, B, &stage_outs[s - first_out], ts);
-        float* t = prev;
-        prev = next;
-        next = t;
-    }
+    hipError_t e = tail_impl(c, feat, B, stage_outs, n_outs, ts, feat_free);
     c->dense_on_tail = false;
     if (e != hipSuccess) return fail(HPE_ERR_HIP, std::string("forward tail: ") + hipGetErrorString(e));
     if (pipelined) {
@@ -1224,6 +1275,24 @@ int hpe_forward_pipelined(hpe_ctx* c, const float* images, int B, const HpeOutpu
     return forward_impl(c, images, B, stage_outs, n_outs, static_cast<hipStream_t>(stream), true);
 }
 
+int hpe_tail(hpe_ctx* c, const float* features, int B, const HpeOutputs* stage_outs, int n_outs, void* stream) {
+    int rc = check_ready(c, B, NEED_REG | NEED_SMPL);
+    if (rc) return rc;
+    if (!features || !stage_outs) return fail(HPE_ERR_INVALID, "null pointer");
+    if (n_outs < 1 || n_outs > c->cfg.num_stage) return fail(HPE_ERR_INVALID, "n_outs must be in [1, num_stage]");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c->tail_pending) {  // shares the regressor / SMPL buffers with a pipelined call's tail
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_tail, 0));
+        c->tail_pending = false;
+    }
+    c->dense_on_tail = true;  // its own split-K workspace: may overlap hpe_encoder of the next batch
+    const hipError_t e = tail_impl(c, features, B, stage_outs, n_outs, st, nullptr);
+    c->dense_on_tail = false;
+    if (e != hipSuccess) return fail(HPE_ERR_HIP, std::string("hpe_tail: ") + hipGetErrorString(e));
+    return HPE_OK;
+}
+
 int hpe_join(hpe_ctx* c, void* stream) {
     if (!c || !c->finalized) return fail(HPE_ERR_STATE, "needs a finalized ctx");
     DeviceGuard g(c->cfg.device);
@@ -1245,14 +1314,13 @@ int hpe_reproject_vertices(const float* verts, const float* cam, int B, int P, f
     return HPE_OK;
 }
 
-int hpe_preprocess_u8(const unsigned char* img, int H, int W, int C, float* out224, int proc_param[5], void* stream) {
-    if (!img || !out224 || !proc_param || H < 1 || W < 1 || (C != 3 && C != 4)) return fail(HPE_ERR_INVALID, "bad argument");
+// preview.py:22-29 / image.py:7-15,17-39 -- all index arithmetic in double like numpy; false if the frame is too thin
+static bool preprocess_geometry(int H, int W, PreprocFrame* f, int proc_param[5]) {
     const int S = HPE_IMG_SIZE;
     const int mx = H > W ? H : W;
-    // preview.py:22-29 / image.py:7-15,17-39 -- all index arithmetic in double like numpy
     const double scale = (mx != S) ? ((double)S / (double)mx) : 1.0;
     const int newH = (int)std::floor(H * scale), newW = (int)std::floor(W * scale);
-    if (newH < 1 || newW < 1) return fail(HPE_ERR_INVALID, "image too thin");
+    if (newH < 1 || newW < 1) return false;
     const double fy = (double)newH / (double)H, fx = (double)newW / (double)W;  // actual_factor [y, x]
     const double cy = std::nearbyint(H / 2.0), cx = std::nearbyint(W / 2.0);     // np.round: half to even
     const int csx = (int)std::nearbyint(cx * fx), csy = (int)std::nearbyint(cy * fy);
@@ -1263,7 +1331,49 @@ int hpe_preprocess_u8(const unsigned char* img, int H, int W, int C, float* out2
     proc_param[2] = start_x + 2 * margin;
     proc_param[3] = start_y + 2 * margin;
     proc_param[4] = S;
-    HIP_TRY(hpe_launch_preprocess_u8(img, H, W, C, newH, newW, start_x, start_y, margin, out224, S, static_cast<hipStream_t>(stream)));
+    f->H = H;
+    f->W = W;
+    f->newH = newH;
+    f->newW = newW;
+    f->start_x = start_x;
+    f->start_y = start_y;
+    return true;
+}
+
+int hpe_preprocess_u8(const unsigned char* img, int H, int W, int C, float* out224, int proc_param[5], void* stream) {
+    if (!img || !out224 || !proc_param || H < 1 || W < 1 || (C != 3 && C != 4)) return fail(HPE_ERR_INVALID, "bad argument");
+    PreprocFrame f{};
+    if (!preprocess_geometry(H, W, &f, proc_param)) return fail(HPE_ERR_INVALID, "image too thin");
+    HIP_TRY(hpe_launch_preprocess_u8(img, H, W, C, f.newH, f.newW, f.start_x, f.start_y, HPE_IMG_SIZE / 2, out224, HPE_IMG_SIZE,
+                                     static_cast<hipStream_t>(stream)));
+    return HPE_OK;
+}
+
+int hpe_preprocess_u8_batch(const unsigned char* frames, const long long* offsets, const int* sizes_hw, int B, int C, float* out,
+                            int* proc_params, void* table_dev, void* stream) {
+    if (!frames || !sizes_hw || !out || !proc_params || B < 1 || (C != 3 && C != 4)) return fail(HPE_ERR_INVALID, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!offsets) {
+        PreprocFrame f{};
+        if (sizes_hw[0] < 1 || sizes_hw[1] < 1 || !preprocess_geometry(sizes_hw[0], sizes_hw[1], &f, proc_params))
+            return fail(HPE_ERR_INVALID, "bad frame size");
+        for (int b = 1; b < B; ++b) memcpy(proc_params + 5 * b, proc_params, 5 * sizeof(int));
+        HIP_TRY(hpe_launch_preprocess_u8_batch(frames, nullptr, f, B, C, HPE_IMG_SIZE / 2, out, HPE_IMG_SIZE, st));
+        return HPE_OK;
+    }
+    if (!table_dev) return fail(HPE_ERR_INVALID, "per-image sizes need table_dev (32 * B bytes of device scratch)");
+    static_assert(sizeof(PreprocFrame) == 32, "table_dev is documented as 32 bytes per frame");
+    std::vector<PreprocFrame> tab((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        if (offsets[b] < 0 || sizes_hw[2 * b] < 1 || sizes_hw[2 * b + 1] < 1 ||
+            !preprocess_geometry(sizes_hw[2 * b], sizes_hw[2 * b + 1], &tab[b], proc_params + 5 * b))
+            return fail(HPE_ERR_INVALID, "bad frame " + std::to_string(b));
+        tab[b].offset = offsets[b];
+    }
+    // pageable source: the runtime stages the bytes before it returns, so `tab` may die at the end of this call
+    HIP_TRY(hipMemcpyAsync(table_dev, tab.data(), tab.size() * sizeof(PreprocFrame), hipMemcpyHostToDevice, st));
+    HIP_TRY(hpe_launch_preprocess_u8_batch(frames, static_cast<const PreprocFrame*>(table_dev), PreprocFrame{}, B, C, HPE_IMG_SIZE / 2, out,
+                                           HPE_IMG_SIZE, st));
     return HPE_OK;
 }
 
@@ -1300,6 +1410,12 @@ int hpe_kp_loss(const float* kp_gt, const float* kp_pred, int B, int K, float* o
 // Loss workspace: sized in hpe_finalize for max_batch images of 224 x 224 and 6890 vertices (what the path produces); any
 // other geometry grows it here -- the one case in which a compute call synchronises (documented in hpe.h).
 static int ensure_loss_ws(hpe_ctx* c, int B, int H, int W, int P) {
+    if (!c->loss_attr_done) {
+        // a ctx that was never finalized (loss operators only): the search kernel's dynamic-LDS attribute is set here
+        HIP_TRY(hpe_losses_init_device());
+        c->mesh_a2b = c->cfg.mesh_a2b >= 0 ? c->cfg.mesh_a2b : hpe_mesh_a2b_mode_from_env();
+        c->loss_attr_done = true;
+    }
     const size_t need = hpe_mesh_loss_ws_floats(B, H, W, P);
     if (need <= c->loss_ws_floats) return HPE_OK;
     HIP_TRY(hipDeviceSynchronize());
@@ -1327,7 +1443,7 @@ int hpe_mesh_loss(hpe_ctx* c, const float* seg, const float* verts2d, int B, int
     DeviceGuard g(c->cfg.device);
     int rc = ensure_loss_ws(c, B, H, W, P);
     if (rc) return rc;
-    HIP_TRY(hpe_launch_mesh_loss(seg, verts2d, B, H, W, P, c->loss_ws, out, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hpe_launch_mesh_loss(seg, verts2d, B, H, W, P, c->loss_ws, out, static_cast<hipStream_t>(stream), c->mesh_a2b, c->loss_counter));
     return HPE_OK;
 }
 
@@ -1353,7 +1469,7 @@ int hpe_val_losses(hpe_ctx* c, const float* seg, const float* kp_gt, const float
         HIP_TRY(hpe_launch_kp_loss(kp_gt, kp2d[s], B * K, out + 4 * s, st));  // writes out[4s .. 4s+2]
         if (mesh)
             HIP_TRY(hpe_launch_mesh_loss_search(verts2d[s], B, H, W, P, c->loss_ws, out + 4 * s + 3, st, tm ? c->lev0[s] : nullptr,
-                                                tm ? c->lev1[s] : nullptr));
+                                                tm ? c->lev1[s] : nullptr, c->mesh_a2b, c->loss_counter));
         else
             HIP_TRY(hipMemsetAsync(out + 4 * s + 3, 0, sizeof(float), st));
     }
@@ -1471,6 +1587,7 @@ int hpe_device_status(hpe_ctx* c, void* stream) {
 int hpe_enable_timing(hpe_ctx* c, int enable) {
     if (!c) return fail(HPE_ERR_INVALID, "null ctx");
     c->timing = enable;
+    c->span_n = 0;
     c->timed_valid = false;
     c->conv_timed_valid = false;
     return HPE_OK;
@@ -1495,6 +1612,28 @@ int hpe_get_timings(hpe_ctx* c, float ms[5]) {
     return HPE_OK;
 }
 
+int hpe_get_span_stats(hpe_ctx* c, float ms[3], int* n_calls) {
+    if (!c || !ms || !n_calls) return fail(HPE_ERR_INVALID, "null argument");
+    if (c->span_n == 0) return fail(HPE_ERR_STATE, "no timed call recorded (hpe_enable_timing first)");
+    DeviceGuard g(c->cfg.device);
+    const unsigned n = c->span_n < (unsigned)hpe_ctx::SPAN_RING ? c->span_n : (unsigned)hpe_ctx::SPAN_RING;
+    double sum = 0.0;
+    float lo = 1e30f, hi = 0.f;
+    for (unsigned i = 0; i < n; ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventSynchronize(c->span1[i]));
+        HIP_TRY(hipEventElapsedTime(&t, c->span0[i], c->span1[i]));
+        sum += t;
+        lo = t < lo ? t : lo;
+        hi = t > hi ? t : hi;
+    }
+    ms[0] = (float)(sum / n);
+    ms[1] = lo;
+    ms[2] = hi;
+    *n_calls = (int)n;
+    return HPE_OK;
+}
+
 int hpe_get_loss_timings(hpe_ctx* c, float ms[2]) {
     if (!c || !ms) return fail(HPE_ERR_INVALID, "null argument");
     if (c->loss_timed_stages == 0) return fail(HPE_ERR_STATE, "no timed hpe_val_losses call recorded (hpe_enable_timing first)");
@@ -1507,6 +1646,12 @@ int hpe_get_loss_timings(hpe_ctx* c, float ms[2]) {
         HIP_TRY(hipEventElapsedTime(&t, c->lev0[s], c->lev1[s]));
         ms[1] += t;
     }
+    return HPE_OK;
+}
+
+int hpe_debug_set_loss_counter(hpe_ctx* c, void* counter_dev) {
+    if (!c) return fail(HPE_ERR_INVALID, "null ctx");
+    c->loss_counter = static_cast<unsigned long long*>(counter_dev);
     return HPE_OK;
 }
 

@@ -118,16 +118,27 @@ hipError_t hpe_launch_orth_proj(const float* X, const float* cam, int B, int P, 
 hipError_t hpe_launch_kp_loss(const float* gt, const float* pred, int n, float* out, hipStream_t st);
 hipError_t hpe_losses_init_device();  // per-device kernel attributes of the loss kernels
 size_t hpe_mesh_loss_ws_floats(int B, int H, int W, int P);
+// a2b_mode: 0 cell-grid search (default), 1 VALU full search, 2 matrix-core full search; counter: optional 2 x u64 (MFMAs issued
+// by the grid / full search)
+int hpe_mesh_a2b_mode_from_env();
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
-                                hipStream_t st);
+                                hipStream_t st, int a2b_mode, unsigned long long* counter);
 // the same in two halves: silhouette compaction + bitmap (once per step), then the searches of one vertex set (once per IEF stage)
 hipError_t hpe_launch_mesh_loss_prepare(const float* seg, int B, int H, int W, int P, float* ws, hipStream_t st);
 // (ev_a2b0 / ev_a2b1: optional events recorded around the pixel -> vertex search, the dominant kernel of the loss)
 hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, int P, float* ws, float* out, hipStream_t st,
-                                       hipEvent_t ev_a2b0, hipEvent_t ev_a2b1);
+                                       hipEvent_t ev_a2b0, hipEvent_t ev_a2b1, int a2b_mode, unsigned long long* counter);
 
 // prepost.hip
 hipError_t hpe_launch_preprocess_u8(const unsigned char* img, int H, int W, int C, int newH, int newW, int start_x, int start_y,
                                     int margin, float* out, int S, hipStream_t st);
+// batch of frames in one launch: frame b at img + (table ? table[b].offset : b * H * W * C); table == nullptr: all frames share the
+// geometry in `uni`
+struct PreprocFrame {
+    long long offset;
+    int H, W, newH, newW, start_x, start_y;
+};
+hipError_t hpe_launch_preprocess_u8_batch(const unsigned char* img, const PreprocFrame* table_dev, PreprocFrame uni, int B, int C, int margin,
+                                          float* out, int S, hipStream_t st);
 hipError_t hpe_launch_shift_verts(const float* verts, const float* cam, int B, int P, float flength, float img_size, float* out,
                                   hipStream_t st);

@@ -173,7 +173,8 @@ __device__ __forceinline__ float mfma_k2_value(float a0, float b0, float a1, flo
 // costs an extra v_accvgpr_read before the VALU can touch it)
 __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __restrict__ pts, const int* __restrict__ counts,
                                                           const float* __restrict__ v2d, int HW, int P, float* __restrict__ partial,
-                                                          int nblk, const int* __restrict__ only_flagged) {
+                                                          int nblk, const int* __restrict__ only_flagged,
+                                                          unsigned long long* __restrict__ mfma_count) {
     if (only_flagged && only_flagged[blockIdx.y] == 0) return;  // image already done by the cell-grid search
     __shared__ __attribute__((aligned(16))) float sX[NN_BT];  // -2 bx
     __shared__ __attribute__((aligned(16))) float sY[NN_BT];  // -2 by
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __rest
             }
         }
     }
+    if (mfma_count && lane == 0) atomicAdd(mfma_count, (unsigned long long)(((P + 31) >> 5) * NN_PG));
     float contrib = 0.f;
 #pragma unroll
     for (int g = 0; g < NN_PG; ++g) {
@@ -310,7 +312,7 @@ template <int CELL, int NPG>
 __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
                                                            const float* __restrict__ v2d, int H, int W, int WW, int P, int Gx, int Gy,
                                                            float* __restrict__ partial, int nblk, int nslots, int* __restrict__ full_search,
-                                                           int min_cells) {
+                                                           int min_cells, unsigned long long* __restrict__ mfma_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char grid_smem[];
     const int NC = Gx * Gy;
     const int Ppad = (P + 31) & ~31;
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         if (__ballot(any_active) == 0ull) return 0.f;
         bool overflow = false;  // more than three chunks tied with the best: the tile takes the explicit (distance, index) pass
         int vmask = 0;  // lane w holds bits 32w .. 32w+31 of the wave's visited-chunk set
+        int nchunk = 0;  // chunks evaluated for this tile (diagnostics counter)
         auto scan = [&](int c0, int c1) {
             const int s = __builtin_amdgcn_readfirstlane(sStart[c0]), e = __builtin_amdgcn_readfirstlane(sStart[c1 + 1]);
             if (e <= s) return;
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                 const int word = __builtin_amdgcn_readlane(vmask, k >> 5);
                 if ((word >> (k & 31)) & 1) continue;
                 vmask |= (lane == (k >> 5)) ? (1 << (k & 31)) : 0;
+                ++nchunk;
                 const float a = hi ? sY[32 * k + l31] : sX[32 * k + l31];
                 f32x16_t qz;
 #pragma unroll
@@ -604,6 +608,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
+        if (mfma_count && lane == 0) atomicAdd(mfma_count, (unsigned long long)(nchunk * NPG));
         return contrib;
     };
     for (int q = next_tile(); q < nq; q = next_tile()) {
@@ -848,7 +853,8 @@ static size_t a2b_grid_lds_bytes(int H, int W, int WW, int P, int Gx, int Gy) {
     return (size_t)((P + 31) & ~31) * 16 + (size_t)(2 * Gx * Gy + 2) * 4 + (size_t)H * WW * 8 + (size_t)((W + 7) / 8) * ((H + 7) / 8) * 4;
 }
 
-typedef void (*A2bGridKernel)(const unsigned long long*, const int*, const float*, int, int, int, int, int, int, float*, int, int, int*, int);
+typedef void (*A2bGridKernel)(const unsigned long long*, const int*, const float*, int, int, int, int, int, int, float*, int, int, int*, int,
+                              unsigned long long*);
 // (cell edge, 32-pixel groups per tile) variants; [0] is the default
 static const struct {
     int cell, npg;
@@ -923,15 +929,16 @@ hipError_t hpe_launch_mesh_loss_prepare(const float* seg, int B, int H, int W, i
 }
 
 // Per-stage half: both nearest-neighbour searches against the prepared silhouette + the reduction.
+int hpe_mesh_a2b_mode_from_env() {
+    // HPE_MESH_A2B: "grid" (default: cell-grid search), "mfma" / "valu" (the full searches, for A/B comparisons)
+    const char* e = getenv("HPE_MESH_A2B");
+    return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0));
+}
+
 hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, int P, float* ws, float* out, hipStream_t st,
-                                       hipEvent_t ev_a2b0, hipEvent_t ev_a2b1) {
+                                       hipEvent_t ev_a2b0, hipEvent_t ev_a2b1, int a2b_mode, unsigned long long* counter) {
     const MeshWs m = mesh_ws_layout(ws, B, H, W, P);
     const int HW = H * W;
-    // HPE_MESH_A2B: "grid" (default: cell-grid search), "mfma" / "valu" (the full searches, for A/B comparisons)
-    static const int a2b_mode = [] {
-        const char* e = getenv("HPE_MESH_A2B");
-        return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0));
-    }();
     // images whose vertices occupy fewer cells than this go to the full search (0: never)
     static const int a2b_min_cells = [] {
         const char* e = getenv("HPE_MESH_A2B_MINCELLS");
@@ -959,16 +966,16 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
         nslice = std::max(1, std::min(nslice, m.nA));
         const int min_cells = a2b_min_cells * (64 / (cell * cell));  // the knob is in 8 x 8-pixel cells
         hipLaunchKernelGGL(a2b_grid_variants[a2b_variant].fn, dim3(nslice, B), dim3(1024), grid_lds, st, m.bits, m.counts, v2d, H, W, m.WW, P,
-                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, min_cells);
+                           Gx, Gy, m.partial, m.nblk, m.nA, m.full_search, min_cells, counter);
         hipError_t eg = hipGetLastError();
         if (eg != hipSuccess) return eg;
         hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk,
-                               (const int*)m.full_search);
+                               (const int*)m.full_search, counter ? counter + 1 : nullptr);
     } else if (a2b_mode == 1)
         hipLaunchKernelGGL(nn_a2b_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk);
     else
         hipLaunchKernelGGL(nn_a2b_mfma_kernel, dim3(m.nA, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk,
-                           (const int*)nullptr);
+                           (const int*)nullptr, counter ? counter + 1 : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_a2b1) (void)hipEventRecord(ev_a2b1, st);
@@ -986,8 +993,8 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
 }
 
 hipError_t hpe_launch_mesh_loss(const float* seg, const float* v2d, int B, int H, int W, int P, float* ws, float* out,
-                                hipStream_t st) {
+                                hipStream_t st, int a2b_mode, unsigned long long* counter) {
     hipError_t e = hpe_launch_mesh_loss_prepare(seg, B, H, W, P, ws, st);
     if (e != hipSuccess) return e;
-    return hpe_launch_mesh_loss_search(v2d, B, H, W, P, ws, out, st, nullptr, nullptr);
+    return hpe_launch_mesh_loss_search(v2d, B, H, W, P, ws, out, st, nullptr, nullptr, a2b_mode, counter);
 }

@@ -42,11 +42,9 @@ __device__ __forceinline__ ResizeAxis axis_coef(int d, int dsize, int ssize) {
     return r;
 }
 
-// out [224,224,3] float; one thread per output pixel
-__global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int H, int W, int C, int newH, int newW, int start_x,
-                                     int start_y, int margin, float* __restrict__ out, int S) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S * S) return;
+// one output pixel of one frame (the body shared by the single-frame and the batched kernel)
+__device__ __forceinline__ void preprocess_pixel(const unsigned char* __restrict__ img, int H, int W, int C, int newH, int newW, int start_x,
+                                                 int start_y, int margin, float* __restrict__ out, int S, int i) {
     const int oy = i / S, ox = i - oy * S;
     // coordinate in the edge-padded scaled image -> clamp back into the scaled image (np.pad mode='edge')
     int sy = start_y + oy - margin, sx = start_x + ox - margin;
@@ -73,6 +71,28 @@ __global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int 
     for (int c = 0; c < 3; ++c) out[(size_t)i * 3 + c] = 2.0f * ((v[c] / 255.0f) - 0.5f);  // preview.py:33
 }
 
+// out [224,224,3] float; one thread per output pixel
+__global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int H, int W, int C, int newH, int newW, int start_x,
+                                     int start_y, int margin, float* __restrict__ out, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * S) return;
+    preprocess_pixel(img, H, W, C, newH, newW, start_x, start_y, margin, out, S, i);
+}
+
+// batch: grid (ceil(S*S / 256), B); frame geometry from the per-image table, or `uni` for a stream of equal frames
+__global__ void preprocess_u8_batch_kernel(const unsigned char* __restrict__ img, const PreprocFrame* __restrict__ table, PreprocFrame uni,
+                                           int C, int margin, float* __restrict__ out, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * S) return;
+    const int b = blockIdx.y;
+    PreprocFrame f = uni;
+    if (table)
+        f = table[b];
+    else
+        f.offset = (long long)b * uni.H * uni.W * C;
+    preprocess_pixel(img + f.offset, f.H, f.W, C, f.newH, f.newW, f.start_x, f.start_y, margin, out + (size_t)b * S * S * 3, S, i);
+}
+
 // vert_shifted[b,v,:] = verts[b,v,:] + [tx, ty, tz],  tz = flength / (0.5 * img_size * s)   (renderer.py:266-271)
 __global__ void shift_verts_kernel(const float* __restrict__ verts, const float* __restrict__ cam, int B, int P, float flength,
                                    float img_size, float* __restrict__ out) {
@@ -93,6 +113,12 @@ hipError_t hpe_launch_preprocess_u8(const unsigned char* img, int H, int W, int 
                                     int margin, float* out, int S, hipStream_t st) {
     hipLaunchKernelGGL(preprocess_u8_kernel, dim3((S * S + 255) / 256), dim3(256), 0, st, img, H, W, C, newH, newW, start_x, start_y,
                        margin, out, S);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_preprocess_u8_batch(const unsigned char* img, const PreprocFrame* table_dev, PreprocFrame uni, int B, int C, int margin,
+                                          float* out, int S, hipStream_t st) {
+    hipLaunchKernelGGL(preprocess_u8_batch_kernel, dim3((S * S + 255) / 256, B), dim3(256), 0, st, img, table_dev, uni, C, margin, out, S);
     return hipGetLastError();
 }
 

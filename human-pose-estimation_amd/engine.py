@@ -34,7 +34,10 @@ def _require_cuda_tensor(t, name, shape_tail=None):
 
 
 class HpeEngine(object):
-    def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3, encoder_dtype="fp32"):
+    def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3, encoder_dtype="fp32", **plan_options):
+        """plan_options: the HpeConfig plan fields of include/hpe.h (n_streams, dual_gemm, stem_fused, wino_min_c, wino_min_items,
+        wino_fused, wino_fused_min_hw, mesh_a2b, wino_f4); unset = -1 = the library default (environment variable, else built-in).
+        They select WHICH kernels run, per context -- two engines with different options can coexist in one process."""
         self.lib = _lib.load()
         torch = _torch()
         if not torch.cuda.is_available():
@@ -46,7 +49,17 @@ class HpeEngine(object):
         if encoder_dtype not in ("fp32", "bf16"):
             raise ValueError("encoder_dtype must be 'fp32' or 'bf16'")
         self.encoder_dtype = encoder_dtype
-        cfg = _lib.HpeConfig(self.device, self.max_batch, self.num_stage, float(bn_eps), 1 if encoder_dtype == "bf16" else 0)
+        cfg = _lib.HpeConfig()
+        self.lib.hpe_config_init(C.byref(cfg))
+        cfg.device, cfg.max_batch, cfg.num_stage, cfg.bn_eps = self.device, self.max_batch, self.num_stage, float(bn_eps)
+        cfg.encoder_dtype = 1 if encoder_dtype == "bf16" else 0
+        for k, v in plan_options.items():
+            if k not in _lib.PLAN_OPTIONS:
+                raise TypeError("unknown plan option %r (known: %s)" % (k, ", ".join(_lib.PLAN_OPTIONS)))
+            if k == "mesh_a2b" and isinstance(v, str):
+                v = {"grid": 0, "valu": 1, "mfma": 2}[v]
+            setattr(cfg, k, int(v))
+        self.plan_options = dict(plan_options)
         h = C.c_void_p()
         _lib.check(self.lib.hpe_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -156,7 +169,9 @@ class HpeEngine(object):
     def forward(self, images, all_stages=False, want=DEFAULT_OUTPUTS, pipelined=False):
         """images [B,224,224,3] cuda float32 -> list (one dict per returned stage) of output tensors.
         pipelined=True: hpe_forward_pipelined (the outputs are complete after ``join()``); used by Predictor.predict for inputs
-        larger than config.batch_size, whose chunks then overlap tail and encoder."""
+        larger than config.batch_size, whose chunks then overlap tail and encoder.  The ctx's tail stream writes the outputs and
+        torch's caching allocator does not know that stream: keep the returned tensors alive until ``join()`` has been called
+        (they are also marked with ``record_stream`` for the tail stream, so a tensor dropped early is not recycled under it)."""
         images = _require_cuda_tensor(images, "images", (224, 224, 3))
         B = images.shape[0]
         n_outs = self.num_stage if all_stages else 1
@@ -167,8 +182,139 @@ class HpeEngine(object):
             outs.append(t)
             arr[i] = o
         fwd = self.lib.hpe_forward_pipelined if pipelined else self.lib.hpe_forward
+        if pipelined:
+            ts = self.tail_stream()
+            for t in outs:
+                for v in t.values():
+                    v.record_stream(ts)
         _lib.check(fwd(self._h, images.data_ptr(), B, arr, n_outs, self._stream()))
         return outs
+
+    def tail(self, features, all_stages=False, want=DEFAULT_OUTPUTS):
+        """The regressor + SMPL half alone (hpe_tail): features [B,2048] from ``encoder()`` -> list of per-stage output dicts."""
+        features = _require_cuda_tensor(features, "features", (2048,))
+        B = features.shape[0]
+        n_outs = self.num_stage if all_stages else 1
+        outs = []
+        arr = (_lib.HpeOutputs * n_outs)()
+        for i in range(n_outs):
+            t, o = self._alloc_outputs(B, want)
+            outs.append(t)
+            arr[i] = o
+        _lib.check(self.lib.hpe_tail(self._h, features.data_ptr(), B, arr, n_outs, self._stream()))
+        return outs
+
+    def make_overlapped_plan(self, B, all_stages=False, want=DEFAULT_OUTPUTS, graph=False, tail_extra=None, n_sets=2):
+        """Steady-state serving as ONE stream-ordered, hipGraph-capturable step per batch (hpe_encoder + hpe_tail):
+
+            step(images_k)  =  fork;  side stream: tail(features of batch k-1) [+ tail_extra(outs)]  ||  encoder(images_k);  join
+
+        i.e. the software pipeline of ``hpe_forward_pipelined`` with the overlap INSIDE the step instead of across calls, so that
+        the whole step (every launch of both branches, the fork / join of the encoder's chunk streams and of the side stream) can
+        be captured once and replayed with one host call.  ``step(images)`` returns the output set of the PREVIOUS batch (None
+        on the first call); ``flush()`` runs the tail of the last batch alone and returns its outputs.  Features alternate
+        between two buffers and outputs between ``n_sets`` sets; ``tail_extra(outs, set_index)`` (e.g. the loss call) is enqueued
+        on the side stream after the tail, inside the capture.  graph=True: two graphs (one per feature buffer parity) per output
+        set rotation are captured after an eager warm-up; images are copied into a static input buffer."""
+        torch = _torch()
+        n_outs = self.num_stage if all_stages else 1
+        sets = []
+        for _ in range(n_sets):
+            outs, arr = [], (_lib.HpeOutputs * n_outs)()
+            for i in range(n_outs):
+                t, o = self._alloc_outputs(B, want)
+                outs.append(t)
+                arr[i] = o
+            sets.append((outs, arr))
+        feats = [self._new(B, 2048) for _ in range(2)]
+        side = torch.cuda.Stream(device=self.tdev)
+        lib, h = self.lib, self._h
+        state = {"k": 0}
+
+        def enqueue(images, k, with_tail, with_enc):
+            cur = torch.cuda.current_stream(self.tdev)
+            if with_tail:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    outs, arr = sets[(k - 1) % n_sets]
+                    _lib.check(lib.hpe_tail(h, feats[(k - 1) & 1].data_ptr(), B, arr, n_outs, C.c_void_p(side.cuda_stream)))
+                    if tail_extra is not None:
+                        tail_extra(outs, (k - 1) % n_sets)
+            if with_enc:
+                _lib.check(lib.hpe_encoder(h, images.data_ptr(), B, feats[k & 1].data_ptr(), self._stream()))
+            if with_tail:
+                cur.wait_stream(side)
+
+        if not graph:
+
+            def step(images):
+                k = state["k"]
+                enqueue(images, k, k > 0, True)
+                state["k"] = k + 1
+                if k > 0:
+                    step.last = (k - 1) % n_sets
+                return sets[(k - 1) % n_sets][0] if k > 0 else None
+
+            def flush():
+                k = state["k"]
+                if k == 0:
+                    return None
+                enqueue(None, k, True, False)
+                state["k"] = 0
+                step.last = (k - 1) % n_sets
+                return sets[(k - 1) % n_sets][0]
+
+            step.flush = flush
+            step.last = None  # index (into step.sets) of the output set of the most recently completed batch
+            step.sets = [s_[0] for s_ in sets]
+            return step
+
+        static_in = torch.zeros((B, 224, 224, 3), dtype=torch.float32, device=self.tdev)
+        self.enable_timing(0)  # event timing cannot be captured
+        # eager warm-up of every launch shape (lazy module loading, workspace growth) before capture
+        warm = torch.cuda.Stream(device=self.tdev)
+        warm.wait_stream(torch.cuda.current_stream(self.tdev))
+        with torch.cuda.stream(warm):
+            enqueue(static_in, 0, False, True)
+            enqueue(static_in, 1, True, True)
+            enqueue(None, 2, True, False)
+        torch.cuda.current_stream(self.tdev).wait_stream(warm)
+        torch.cuda.synchronize(self.tdev)
+        period = 2 * n_sets // (2 if n_sets % 2 == 0 else 1)  # lcm(2, n_sets): (feature parity, output set) repeats with this period
+
+        def capture(k, with_tail, with_enc):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue(static_in, k, with_tail, with_enc)
+            return g
+
+        g_first = capture(0, False, True)
+        g_steady = [capture(period + r, True, True) for r in range(period)]  # index r == k % period, k >= 1
+        g_flush = [capture(period + r, True, False) for r in range(period)]
+
+        def step(images):
+            k = state["k"]
+            static_in.copy_(images, non_blocking=True)
+            (g_first if k == 0 else g_steady[k % period]).replay()
+            state["k"] = k + 1
+            if k > 0:
+                step.last = (k - 1) % n_sets
+            return sets[(k - 1) % n_sets][0] if k > 0 else None
+
+        def flush():
+            k = state["k"]
+            if k == 0:
+                return None
+            g_flush[k % period].replay()
+            state["k"] = 0
+            step.last = (k - 1) % n_sets
+            return sets[(k - 1) % n_sets][0]
+
+        step.flush = flush
+        step.last = None
+        step.sets = [s_[0] for s_ in sets]
+        step.graphs = (g_first, g_steady, g_flush)  # keep alive
+        return step
 
     def tail_stream(self):
         """torch view of the ctx's tail stream (hpe_tail_stream): consumers of a pipelined plan's outputs enqueue there."""
@@ -335,6 +481,19 @@ class HpeEngine(object):
         ms = (C.c_float * 5)()
         _lib.check(self.lib.hpe_get_timings(self._h, ms))
         return dict(encoder_ms=ms[0], conv_ms=ms[1], regress_smpl_ms=ms[2], total_ms=ms[4])
+
+    def span_stats(self):
+        """Encoder span over all timed calls since enable_timing (hpe_get_span_stats): dict(mean_ms, min_ms, max_ms, calls)."""
+        ms = (C.c_float * 3)()
+        n = C.c_int()
+        _lib.check(self.lib.hpe_get_span_stats(self._h, ms, C.byref(n)))
+        return dict(mean_ms=ms[0], min_ms=ms[1], max_ms=ms[2], calls=n.value)
+
+    def set_loss_counter(self, counter=None):
+        """counter: int64 CUDA tensor of 2 elements (zeroed by the caller) that the pixel -> vertex searches add their MFMA counts
+        to ([0] cell-grid search, [1] full search; 1024 (pixel, vertex) pairs per MFMA); None disables."""
+        _lib.check(self.lib.hpe_debug_set_loss_counter(self._h, None if counter is None else counter.data_ptr()))
+        self._loss_counter = counter  # keep alive
 
     def loss_timings(self):
         ms = (C.c_float * 2)()

@@ -65,7 +65,7 @@ class Predictor(object):
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self.engine = _engine.HpeEngine(
             device=device, max_batch=self.batch_size, num_stage=self.num_stage, bn_eps=getattr(config, "bn_eps", 1e-3),
-            encoder_dtype=getattr(config, "encoder_dtype", "fp32"),
+            encoder_dtype=getattr(config, "encoder_dtype", "fp32"), **(getattr(config, "plan_options", None) or {}),
         )
         # ---- SMPL (reference :55)
         if smpl_model is None:
@@ -139,10 +139,14 @@ class Predictor(object):
         B = images.shape[0]
         chunks = []
         many = B > self.batch_size  # several engine calls: software-pipeline them (tail of chunk k under the encoder of chunk k+1)
-        for lo in range(0, B, self.batch_size):
-            chunks.append(self.engine.forward(images[lo : lo + self.batch_size], all_stages=all_stages, pipelined=many))
-        if many:
-            self.engine.join()  # the caller's stream waits for the last tail: results are then ordered like any torch op
+        try:
+            for lo in range(0, B, self.batch_size):
+                chunks.append(self.engine.forward(images[lo : lo + self.batch_size], all_stages=all_stages, pipelined=many))
+        finally:
+            # the caller's stream waits for the last tail: results are then ordered like any torch op -- also when a later chunk
+            # raised, so that the earlier chunks' outputs are not freed (and recycled by the allocator) under a tail still writing
+            if many:
+                self.engine.join()
         if len(chunks) == 1:
             stages = chunks[0]
         else:

@@ -175,9 +175,18 @@ def make_encoder_params(seed=1, trivial_bn=False):
     return p
 
 
-def make_regressor_params(seed=2):
+def make_regressor_params(seed=2, variant="survey"):
     """Keras Dense layouts: dense_i/kernel [in,out], dense_i/bias [out]; glorot-uniform for the first
-    two, U(+-sqrt(0.06/1109)) for the last (reference: src/models.py:71-72)."""
+    two, U(+-sqrt(0.06/1109)) for the last (reference: src/models.py:71-72).
+
+    variant="survey": exactly that.  On random-init encoder features (mean 2.7, no training) its three IEF
+    steps each move the camera scale by about -0.31: s = 0.9 -> 0.59 -> 0.28 -> -0.03, so that kp2d = s (x + t) of the last
+    stage is a cancelled quantity (RMS 6e-3) on which any fp32 implementation, the fp32 oracle included, sits ~5e-5 from fp64.
+    variant="bounded": the same draws (same seed, same shapes) with the last layer's kernel scaled by 0.25 -- the step a trained
+    regressor takes is small -- which keeps s in [0.5, 1.2] over the three stages (0.83, 0.76, 0.69): the well-conditioned input
+    on which kp2d is held to a fixed 1e-4 on its own scale, and on which the projected mesh covers the silhouette at every stage."""
+    if variant not in ("survey", "bounded"):
+        raise ValueError("variant must be 'survey' or 'bounded'")
     g = _rng(seed)
     dims = [(2133, 1024), (1024, 1024), (1024, 85)]
     p = {}
@@ -185,6 +194,8 @@ def make_regressor_params(seed=2):
         lim = math.sqrt(6.0 / (fi + fo)) if i < 2 else math.sqrt(3.0 * 0.02 / (1024 + 85))
         p["dense_%d/kernel" % i] = g.uniform(-lim, lim, (fi, fo)).astype(np.float32)
         p["dense_%d/bias" % i] = g.normal(0, 0.01, fo).astype(np.float32)
+    if variant == "bounded":
+        p["dense_2/kernel"] = (p["dense_2/kernel"] * np.float32(0.25)).astype(np.float32)
     return p
 
 

@@ -57,7 +57,23 @@ typedef struct HpeConfig {
     int num_stage;  /* IEF iterations; reference default 3 (src/config.py:39) */
     float bn_eps;   /* BatchNorm epsilon: 1e-3 (keras_applications 1.0.8) or 1.001e-5 (tf.keras >= 2.2) */
     int encoder_dtype; /* 0 = fp32 MFMA (default), 1 = bf16 MFMA with fp32 accumulate (config 4) */
+    /* Plan options that change WHICH kernels run (and therefore the rounding of the result, never its meaning).  -1 = the
+     * default: the environment variable named on the right if it is set, else the built-in value.  Fill the struct with
+     * hpe_config_init() first; two contexts with different options can live in one process. */
+    int n_streams;         /* HPE_STREAMS          concurrent batch-chunk streams of the encoder, 1..4 (2) */
+    int dual_gemm;         /* HPE_DUAL             conv_block expand + projection shortcut as one dual-source GEMM (1) */
+    int stem_fused;        /* HPE_STEM_FUSED       conv1 + BN + ReLU + max-pool as one kernel (1); 0 = pad / im2col GEMM / pool */
+    int wino_min_c;        /* HPE_WINO_MINC        3x3 layers with >= this many channels run as Winograd (128); 0 = direct conv everywhere */
+    int wino_min_items;    /* HPE_WINO_MIN_ITEMS   ... when the launch has >= this many work items (128) */
+    int wino_fused;        /* HPE_WINO_FUSED       input transform fused into the Winograd GEMM on the large maps (1) */
+    int wino_fused_min_hw; /* HPE_WINO_FUSED_MINHW smallest map side on the fused path (28) */
+    int mesh_a2b;          /* HPE_MESH_A2B         pixel -> vertex search of the mesh loss: 0 cell grid (default), 1 VALU full
+                            *                      search, 2 matrix-core full search */
+    int wino_f4;           /* HPE_WINO_F4          3x3 layers on the 56x56 / 28x28 maps as Winograd F(4x4,3x3) */
 } HpeConfig;
+
+/* defaults: device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1 */
+void hpe_config_init(HpeConfig* cfg);
 
 /* SMPL constants as the reference holds them after SMPL.__init__ (src/tf_smpl/batch_smpl.py:31-81),
  * as dense host arrays in the pickle's own layouts. */
@@ -127,6 +143,12 @@ int hpe_forward(hpe_ctx* ctx, const float* images_dev, int B, const HpeOutputs* 
  * wrote it.  Per-batch latency is that of hpe_forward; throughput gains the tail time (fp32 3 %, bf16 encoder 10 %). */
 int hpe_forward_pipelined(hpe_ctx* ctx, const float* images_dev, int B, const HpeOutputs* stage_outs, int n_outs, void* stream);
 int hpe_join(hpe_ctx* ctx, void* stream);
+/* The regressor + SMPL half of hpe_forward alone: features_dev [B,2048] (what hpe_encoder wrote) -> stage_outs as in hpe_forward
+ * (src/predictor.py:126-148).  With hpe_encoder it lets a caller software-pipeline batches inside ONE stream-ordered step that a
+ * hipGraph can capture -- fork; hpe_tail(features of batch k) on a side stream || hpe_encoder(images of batch k+1); join --
+ * where hpe_forward_pipelined keeps its tail stream outside the caller's ordering and cannot be captured.  Uses the tail's own
+ * split-K workspace, so it may run concurrently with hpe_encoder of the same ctx (and with nothing else of it). */
+int hpe_tail(hpe_ctx* ctx, const float* features_dev, int B, const HpeOutputs* stage_outs, int n_outs, void* stream);
 /* the ctx's tail stream (hipStream_t) for enqueuing consumers of a pipelined call's outputs without stalling `stream` */
 void* hpe_tail_stream(hpe_ctx* ctx);
 
@@ -171,6 +193,13 @@ int hpe_val_losses(hpe_ctx* ctx, const float* seg_dev, const float* kp_gt_dev, c
  * fused: img_dev uint8 [H,W,C] (C = 3 or 4, RGB first) -> out224_dev float [224,224,3].
  * proc_param (host, out) = {start_pt.x, start_pt.y, end_pt.x, end_pt.y, img_size}; scale = 224 / max(H, W). */
 int hpe_preprocess_u8(const unsigned char* img_dev, int H, int W, int C, float* out224_dev, int proc_param[5], void* stream);
+/* The same for a batch of frames in ONE launch.  frames_dev: uint8 frames in one device buffer; frame i starts at byte
+ * offsets[i] and is [sizes_hw[2i], sizes_hw[2i+1], C].  offsets == NULL: B frames of one size sizes_hw[0] x sizes_hw[1], back to
+ * back (a camera / video stream) -- then no per-image table is needed and table_dev may be NULL.  Otherwise table_dev is a
+ * caller-owned device scratch of >= 32 * B bytes; the per-image table is copied into it from pageable host memory on
+ * `stream` (not capturable).  out_dev [B,224,224,3] float, proc_params (host, out) [B][5] as hpe_preprocess_u8. */
+int hpe_preprocess_u8_batch(const unsigned char* frames_dev, const long long* offsets, const int* sizes_hw, int B, int C,
+                            float* out_dev, int* proc_params, void* table_dev, void* stream);
 /* get_original (src/util/renderer.py:260-283): vert_shifted_dev [B,P,3] = verts + [tx, ty, 500 / (0.5*img_size*s)];
  * cam_for_render (host, out) = {flength/scale, principal point x, y in the original image};
  * kp_original_host [B*K*2] = (joints2d_host + start_pt - img_size/2) / scale (both optional host arrays). */
@@ -210,9 +239,16 @@ int hpe_enable_timing(hpe_ctx* ctx, int level);
  * the last check (today only the opt-in HPE_WINO_STREAMK path can: a bounded inter-workgroup wait that timed out). */
 int hpe_device_status(hpe_ctx* ctx, void* stream);
 int hpe_get_timings(hpe_ctx* ctx, float ms[5]);
+/* Encoder span (first launch to last completion on `stream`, HIP events) over ALL timed hpe_forward* / hpe_encoder calls since
+ * hpe_enable_timing (the last 64 at most): ms[0] mean, ms[1] min, ms[2] max; *n_calls = calls averaged.  Synchronises. */
+int hpe_get_span_stats(hpe_ctx* ctx, float ms[3], int* n_calls);
 /* last timed hpe_val_losses call: ms[0] = whole call, ms[1] = sum over the stages of the pixel -> nearest-vertex search
  * (nn_a2b_mfma_kernel, the dominant kernel of the mesh loss) */
 int hpe_get_loss_timings(hpe_ctx* ctx, float ms[2]);
+/* Work counter of the pixel -> vertex search: while counter_dev (device, 2 x u64, caller-zeroed) is set, every hpe_val_losses /
+ * hpe_mesh_loss call adds the v_mfma_f32_32x32x2_f32 instructions it issues (1024 (pixel, vertex) pairs each) to
+ * counter_dev[0] (cell-grid search) and counter_dev[1] (full search).  NULL disables (the default). */
+int hpe_debug_set_loss_counter(hpe_ctx* ctx, void* counter_dev);
 /* per-conv-layer milliseconds of the last level-2 timed call: ms53[HPE_NUM_CONV] */
 int hpe_get_conv_timings(hpe_ctx* ctx, float* ms53);
 

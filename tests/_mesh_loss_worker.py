@@ -1,6 +1,7 @@
-"""Child process of tests/test_gpu_parity.py::test_mesh_loss_grid_search_equals_full_search: the mesh reprojection loss of a
-fixed set of seeded cases, with the pixel -> vertex search selected by HPE_MESH_A2B in the environment (the knob is read once
-per process).  Prints one JSON list of per-image losses per case."""
+"""Cases of tests/test_gpu_parity.py::test_mesh_loss_grid_search_equals_full_search: the mesh reprojection loss of a fixed set of
+seeded cases, evaluated by a loss-only context (never finalized: SMPL / networks are not needed for the loss operators) whose
+pixel -> vertex search is selected by the ``mesh_a2b`` plan option (HpeConfig).  ``python _mesh_loss_worker.py [grid|mfma|valu]``
+prints one JSON dict of per-image losses per case."""
 import json
 import os
 import sys
@@ -43,23 +44,19 @@ def cases():
     return out
 
 
-def main():
-    class Cfg(object):
-        img_size, num_stage, batch_size, data_format = 224, 3, 6, "NHWC"
-        checkpoint_dir = smpl_model_path = None
-
-    pred = hpe_amd.Predictor(Cfg(), smpl_model=synthetic.make_smpl_model(), mean_params=synthetic.make_mean_params(),
-                             encoder_params=synthetic.make_encoder_params(), regressor_params=synthetic.make_regressor_params())
+def run(mode):
+    eng = hpe_amd.HpeEngine(device=0, max_batch=6, mesh_a2b=mode)
     res = {}
     for name, seg, v in cases():
         per_image = []
         for b in range(seg.shape[0]):
-            val = hpe_amd.mesh_reprojection_loss(pred.engine, torch.from_numpy(seg[b:b + 1]).cuda(), torch.from_numpy(v[b:b + 1]).cuda())
+            val = hpe_amd.mesh_reprojection_loss(eng, torch.from_numpy(seg[b:b + 1]).cuda(), torch.from_numpy(v[b:b + 1]).cuda())
             per_image.append(float(val))
-        both = float(hpe_amd.mesh_reprojection_loss(pred.engine, torch.from_numpy(seg).cuda(), torch.from_numpy(v).cuda()))
+        both = float(hpe_amd.mesh_reprojection_loss(eng, torch.from_numpy(seg).cuda(), torch.from_numpy(v).cuda()))
         res[name] = {"per_image": per_image, "batch": both}
-    print("MESH_LOSS_JSON " + json.dumps(res))
+    eng.close()
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    print("MESH_LOSS_JSON " + json.dumps(run(sys.argv[1] if len(sys.argv) > 1 else "grid")))

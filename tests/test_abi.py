@@ -30,6 +30,24 @@ def test_header_and_binding_agree(lib):
         assert hasattr(lib, name), "library does not export %s" % name
 
 
+def test_config_struct_matches_header(lib):
+    """HpeConfig: the ctypes mirror has the header's fields in the header's order (all 4-byte scalars), and
+    hpe_config_init fills the documented defaults with every plan option at -1 (= environment variable, else built-in)."""
+    import ctypes as C
+
+    txt = open(os.path.join(ROOT, "include", "hpe.h")).read()
+    body = txt[txt.index("typedef struct HpeConfig {"):txt.index("} HpeConfig;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int|float)\s+([a-z_0-9]+)\s*;", body)
+    assert fields == [f[0] for f in _lib.HpeConfig._fields_]
+    assert C.sizeof(_lib.HpeConfig) == 4 * len(fields)
+    assert tuple(fields[5:]) == _lib.PLAN_OPTIONS
+    cfg = _lib.HpeConfig()
+    lib.hpe_config_init(C.byref(cfg))
+    assert (cfg.device, cfg.max_batch, cfg.num_stage, cfg.encoder_dtype) == (0, 8, 3, 0) and abs(cfg.bn_eps - 1e-3) < 1e-9
+    assert all(getattr(cfg, k) == -1 for k in _lib.PLAN_OPTIONS)
+
+
 def test_layer_table_matches_host_spec(lib):
     import ctypes as C
 

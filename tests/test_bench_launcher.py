@@ -32,3 +32,33 @@ def test_launcher_is_bypassed_under_a_launcher_env():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=4 does not match --gpus 2" in r.stderr
+
+
+def test_assets_roundtrip_and_cpulist(tmp_path):
+    """N > 1: the synthetic weights are generated once per node and handed to the ranks as one .npz in /dev/shm; loading it must
+    give back bit-identical arrays with their dtypes (the SMPL kintree is uint32).  parse_cpulist reads sysfs cpulists."""
+    import importlib.util
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert bench.parse_cpulist("") == []
+    from hpe_amd import synthetic
+
+    a = dict(smpl=synthetic.make_smpl_model(), reg=synthetic.make_regressor_params(), reg_bounded=synthetic.make_regressor_params(variant="bounded"),
+             mean=synthetic.make_mean_params())
+    path = str(tmp_path / "assets.npz")
+    bench.save_assets(a, path)
+    b = bench.load_assets(path)
+    assert set(b) == set(a)
+    for grp in a:
+        assert set(a[grp]) == set(b[grp])
+        for k in a[grp]:
+            x, y = np.asarray(a[grp][k]), b[grp][k]
+            assert x.dtype == y.dtype and np.array_equal(x, y), (grp, k)
+    # the bounded variant is the survey draw with a smaller last-layer step, nothing else
+    assert np.array_equal(a["reg"]["dense_0/kernel"], a["reg_bounded"]["dense_0/kernel"])
+    assert np.allclose(a["reg_bounded"]["dense_2/kernel"], 0.25 * a["reg"]["dense_2/kernel"])

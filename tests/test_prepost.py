@@ -52,6 +52,32 @@ def test_preprocess_matches_oracle(shape):
 
 
 @pytest.mark.gpu
+def test_preprocess_batch_matches_oracle():
+    """hpe_preprocess_u8_batch: one launch for a batch -- frames of different sizes through the per-image table, and a stream
+    of equal frames (no table) -- bit-equal to the oracle's per-image preprocess_image and to the single-frame kernel."""
+    import hpe_amd
+
+    shapes = [(224, 224, 3), (480, 640, 3), (100, 37, 3), (300, 500, 3), (224, 100, 3), (721, 333, 3)]
+    imgs = [_img(*sh, seed=7 + i) for i, sh in enumerate(shapes)]
+    out, params = hpe_amd.preprocess_batch(imgs)
+    assert tuple(out.shape) == (len(imgs), 224, 224, 3)
+    for i, im in enumerate(imgs):
+        ref, pp_ref, _ = P.preprocess_image(im)
+        assert tuple(params[i]["start_pt"]) == tuple(pp_ref["start_pt"]) and tuple(params[i]["end_pt"]) == tuple(pp_ref["end_pt"])
+        assert abs(params[i]["scale"] - pp_ref["scale"]) < 1e-12
+        np.testing.assert_allclose(out[i].cpu().numpy(), ref.astype(np.float32), rtol=0, atol=1e-6)
+        one, _, _ = hpe_amd.preprocess_image(im)
+        np.testing.assert_array_equal(out[i].cpu().numpy(), one.cpu().numpy())
+    for sh in ((224, 224, 3), (360, 480, 4)):
+        vid = np.stack([_img(*sh, seed=40 + k) for k in range(5)])
+        out, params = hpe_amd.preprocess_batch(vid)
+        for k in range(5):
+            ref, pp_ref, _ = P.preprocess_image(vid[k])
+            assert tuple(params[k]["start_pt"]) == tuple(pp_ref["start_pt"])
+            np.testing.assert_allclose(out[k].cpu().numpy(), ref.astype(np.float32), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_get_original_matches_oracle():
     import torch
 
