@@ -14,47 +14,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define BKE 64  // bf16 elements per k-slab (128 B)
-#define RF 32   // floats per staged LDS row (128 B)
+#include "bf16_rows.h"
 
 namespace {
-
-struct RowB {
-    int base;  // element offset (bf16 elements) of this lane's 16-B chunk in slab 0
-    unsigned mask;
-};
-
-template <int MODE>
-__device__ __forceinline__ RowB make_row_b(const GemmArgs& p, int m, int lc) {
-    RowB r;
-    r.mask = 0x1ffu;
-    if (m >= p.M) m = p.M - 1;
-    if (MODE == GEMM_DENSE || MODE == GEMM_DUAL) {
-        r.base = m * p.lda + lc * 8;
-    } else {
-        const int hw = p.Ho * p.Wo;
-        const int b = m / hw;
-        const int rem = m - b * hw;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
-        if (MODE == GEMM_STRIDED) {
-            r.base = ((b * p.Hi + ho * p.stride) * p.Wi + wo * p.stride) * p.Cin + lc * 8;
-        } else if (MODE == GEMM_CONV3) {
-            r.base = ((b * p.Hi + ho) * p.Wi + wo) * p.Cin + lc * 8;
-            unsigned mk = 0;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dh = tap / 3 - 1, dw = tap % 3 - 1;
-                if ((unsigned)(ho + dh) < (unsigned)p.Hi && (unsigned)(wo + dw) < (unsigned)p.Wi) mk |= 1u << tap;
-            }
-            r.mask = mk;
-        } else {
-            // STEM: padded input [B,Hi,Wi,4] bf16; one slab = kernel rows (2s, 2s+1), each 8 px x 4 ch = 64 B
-            r.base = ((b * p.Hi + 2 * ho + (lc >> 2)) * p.Wi + 2 * wo) * 4 + (lc & 3) * 8;
-        }
-    }
-    return r;
-}
 
 struct SlabB {
     int off, tap, cs;
@@ -77,9 +39,6 @@ __device__ __forceinline__ void slab_advance_b(const GemmArgs& p, SlabB& sp) {
         sp.off += 2 * p.Wi * 4;
     }
 }
-
-// s_waitcnt vmcnt(n), n <= 63, everything else unconstrained (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
-#define HPE_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
 // NS = LDS ring depth: NS - 1 slabs in flight behind counted vmcnt waits and a raw s_barrier (one barrier per slab).  NS = 2 is
 // the shipped configuration.  NS = 3 (HPE_NS_BF16=3, kept for the 128x128 and 256x128 tiles) was the experiment "is the slab DMA
@@ -409,6 +368,14 @@ __global__ void avgpool_bf16_kernel(const bf16x8* __restrict__ x, float* __restr
     for (int u = 0; u < 8; ++u) y[(long)b * ldy + c * 8 + u] = s[u] * inv;
 }
 
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (__bf16)x[i];
+}
+
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+
 inline int grid_for(long total, int block, int cap = 2048) {
     long g = (total + block - 1) / block;
     if (g > cap) g = cap;
@@ -419,6 +386,7 @@ inline int grid_for(long total, int block, int cap = 2048) {
 }  // namespace
 
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ns, hipStream_t st) {
+    if (tile == TILE_P8_256x256) return hpe_launch_gemm_bf16_p8(p, mode, st);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BKE) != 0 || (p.ldw % 8) != 0 || p.ldw < p.K) return hipErrorInvalidValue;
     if (!p.x || !p.w || !p.y || !p.scale || !p.shift || !p.zero) return hipErrorInvalidValue;
     if ((p.ldy % 8) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
@@ -449,6 +417,16 @@ hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ns, hipStrea
             return launch_mode_b<GEMM_DUAL>(p, tile, ns, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t hpe_launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t st) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, x, reinterpret_cast<__bf16*>(y), n);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t st) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(x), y, n);
+    return hipGetLastError();
 }
 
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st) {

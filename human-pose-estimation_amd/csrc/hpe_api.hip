@@ -128,6 +128,9 @@ struct TileKnobs {
     int force_expand = -1;   // HPE_EXPAND_TILE: fp32 tile of the identity-block expand layers (experiment knob)
     int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
     int bf16_rules = 1;      // HPE_BF16_RULES=0: the round-1 tile rule (128x128 / 64x128 by grid size, double buffer)
+    int bf16_p8 = 0;         // HPE_BF16_P8: layer kinds that take the 256 x 256 phase-interleaved kernel (bit mask, see pick_bf16)
+    int bf16_p8_min_n = 256; // HPE_BF16_P8_MINN
+    int bf16_p8_min_k = 512; // HPE_BF16_P8_MINK
 };
 
 struct hpe_ctx {
@@ -268,8 +271,15 @@ struct Bf16Plan {
 //    and residual loads (res2b_branch2c 0.273 -> 0.182 ms = 5.1 TB/s, res3* 0.157 -> 0.108, res4* 0.079 -> 0.062, res5* 0.061 -> 0.048)
 //  * everything with a long k axis on the small maps (stage 5: M = 49 B): 256x128, 8 waves (res5*_branch2b 0.112 -> 0.083 ms)
 //  * otherwise 128x128 while that still gives >= 512 workgroups, else 64x128
-Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expand, bool concurrent = false) {
+Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expand, bool concurrent = false, int mode = GEMM_DENSE) {
     Bf16Plan pl{TILE_128x64, 2};
+    // 256 x 256 phase-interleaved kernel (conv_gemm_bf16_p8.hip), per layer kind -- bits of bf16_p8:
+    //   1: 3x3 layers with N == 256 (stage 4), 2: 3x3 layers with N >= 512 (stage 5), 4: 1x1 / strided layers,
+    //   8: dual-source launches with N >= 2048 (res5a), 16: the other dual-source launches
+    if (kn.bf16_p8 && N >= kn.bf16_p8_min_n && N % 256 == 0 && K >= kn.bf16_p8_min_k && !residual_expand) {
+        const int bit = mode == GEMM_CONV3 ? (N == 256 ? 1 : 2) : (mode == GEMM_DUAL ? (N >= 2048 ? 8 : 16) : 4);
+        if (kn.bf16_p8 & bit) return Bf16Plan{TILE_P8_256x256, 2};
+    }
     if (N > 64) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         pl.tile = t128 >= ((concurrent || kn.concurrent_tiles) ? kn.bf16_128_min_tiles : 512) ? TILE_128x128 : TILE_64x128;
@@ -367,7 +377,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     }
     if (c->bf16) {
         p.cin_slabs = s.cin / 64;
-        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin, (flags & CONV_CONCURRENT) != 0);
+        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin, (flags & CONV_CONCURRENT) != 0, mode);
         return hpe_launch_gemm_bf16(p, mode, pl.tile, pl.ns, st);
     }
     return hpe_launch_gemm(p, mode, pick_tile(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin, (flags & CONV_CONCURRENT) != 0), st);
@@ -405,7 +415,7 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
         p.partial_floats = c->partial_floats;
     }
     if (c->bf16) {
-        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, false, (flags & CONV_CONCURRENT) != 0);
+        const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, false, (flags & CONV_CONCURRENT) != 0, GEMM_DUAL);
         return hpe_launch_gemm_bf16(p, GEMM_DUAL, pl.tile, pl.ns, st);
     }
     return hpe_launch_gemm(p, GEMM_DUAL, pick_tile(c->knobs, p.M, p.N, p.K, false, (flags & CONV_CONCURRENT) != 0), st);
@@ -618,7 +628,7 @@ void hpe_config_init(HpeConfig* cfg) {
     cfg->bn_eps = 1e-3f;
     cfg->encoder_dtype = 0;
     cfg->n_streams = cfg->dual_gemm = cfg->stem_fused = cfg->wino_min_c = cfg->wino_min_items = cfg->wino_fused = -1;
-    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = -1;
+    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->bf16_p8 = -1;
 }
 
 int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
@@ -817,6 +827,11 @@ static int finalize_impl(hpe_ctx* c) {
         c->knobs.force_ns_bf16 = e ? atoi(e) : -1;
         e = getenv("HPE_BF16_RULES");
         c->knobs.bf16_rules = e ? atoi(e) : 1;
+        c->knobs.bf16_p8 = opt(c->cfg.bf16_p8, "HPE_BF16_P8", c->knobs.bf16_p8);
+        e = getenv("HPE_BF16_P8_MINN");
+        if (e) c->knobs.bf16_p8_min_n = atoi(e);
+        e = getenv("HPE_BF16_P8_MINK");
+        if (e) c->knobs.bf16_p8_min_k = atoi(e);
         // per-device function attributes (dynamic LDS above 64 KB) of the Winograd and stem kernels
         HIP_TRY(hpe_wino_init_device());
         HIP_TRY(hpe_stem_fused_init_device());
@@ -1484,9 +1499,18 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
     int rc = check_ready(c, B, NEED_ENC);
     if (rc) return rc;
     if (idx < 0 || idx >= HPE_NUM_CONV || !x || !y) return fail(HPE_ERR_INVALID, "bad argument");
-    if (c->bf16) return fail(HPE_ERR_STATE, "hpe_debug_conv works on fp32 contexts only");
     DeviceGuard g(c->cfg.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c->bf16) {
+        if (idx == 0) return fail(HPE_ERR_STATE, "hpe_debug_conv: conv1 of a bf16 context runs inside the fused stem only");
+        const ConvSpec& s = specs()[idx];
+        const long nin = (long)B * s.hin * s.hin * s.cin, nout = (long)B * s.hout * s.hout * s.cout;
+        HIP_TRY(hpe_launch_f32_to_bf16(x, c->X0, nin, st));
+        if (residual) HIP_TRY(hpe_launch_f32_to_bf16(residual, c->SC, nout, st));
+        HIP_TRY(run_conv(c, idx, c->X0, B, residual ? c->SC : nullptr, relu, c->X1, st));
+        HIP_TRY(hpe_launch_bf16_to_f32(c->X1, y, nout, st));
+        return HPE_OK;
+    }
     const float* in = x;
     if (idx == 0) {
         HIP_TRY(hpe_launch_pad_input(x, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));

@@ -7,7 +7,8 @@
 // (row pitch lda), the rest from the strided NHWC tensor x2 (geometry in Hi / Wi / Cin / Ho / Wo / stride) -- the last 1x1
 // convolution of a ResNet conv_block and its projection shortcut as ONE launch (weights concatenated along k, BN scales folded in)
 enum GemmMode { GEMM_DENSE = 0, GEMM_STRIDED = 1, GEMM_CONV3 = 2, GEMM_STEM = 3, GEMM_DUAL = 4 };
-enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3, TILE_128x128_W8 = 4, TILE_128x64_W8 = 5, TILE_256x128_W8 = 6 };
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3, TILE_128x128_W8 = 4, TILE_128x64_W8 = 5, TILE_256x128_W8 = 6,
+                TILE_P8_256x256 = 7 /* bf16 only: the phase-interleaved 8-wave kernel of conv_gemm_bf16_p8.hip */ };
 
 // Arguments of the implicit-GEMM kernel (conv_gemm.hip).  All offsets are in floats.
 struct GemmArgs {
@@ -59,6 +60,10 @@ hipError_t hpe_launch_nhwc_to_slab8(const float* x, float* xs, long M, int C, hi
 
 // conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ring_depth, hipStream_t st);  // ring_depth 2..4 LDS slab buffers
+// conv_gemm_bf16_p8.hip: 256 x 256 x 64 tile, 8 waves, phase-interleaved main loop, split-K through p.partial (DENSE / STRIDED / CONV3 / DUAL)
+hipError_t hpe_launch_gemm_bf16_p8(GemmArgs p, int mode, hipStream_t st);
+hipError_t hpe_launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);  // round to nearest even
+hipError_t hpe_launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t st);
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
 hipError_t hpe_launch_maxpool_bf16(const void* x, void* y, int B, int H, int C, hipStream_t st);
 hipError_t hpe_launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, int ldy, hipStream_t st);

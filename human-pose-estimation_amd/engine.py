@@ -227,7 +227,8 @@ class HpeEngine(object):
                 arr[i] = o
             sets.append((outs, arr))
         feats = [self._new(B, 2048) for _ in range(2)]
-        side = torch.cuda.Stream(device=self.tdev)
+        # the side branch runs on the ctx's own tail stream: a process should keep <= 4 busy HIP streams ("hardware queues")
+        side = self.tail_stream()
         lib, h = self.lib, self._h
         state = {"k": 0}
 
@@ -272,13 +273,9 @@ class HpeEngine(object):
         static_in = torch.zeros((B, 224, 224, 3), dtype=torch.float32, device=self.tdev)
         self.enable_timing(0)  # event timing cannot be captured
         # eager warm-up of every launch shape (lazy module loading, workspace growth) before capture
-        warm = torch.cuda.Stream(device=self.tdev)
-        warm.wait_stream(torch.cuda.current_stream(self.tdev))
-        with torch.cuda.stream(warm):
-            enqueue(static_in, 0, False, True)
-            enqueue(static_in, 1, True, True)
-            enqueue(None, 2, True, False)
-        torch.cuda.current_stream(self.tdev).wait_stream(warm)
+        enqueue(static_in, 0, False, True)
+        enqueue(static_in, 1, True, True)
+        enqueue(None, 2, True, False)
         torch.cuda.synchronize(self.tdev)
         period = 2 * n_sets // (2 if n_sets % 2 == 0 else 1)  # lcm(2, n_sets): (feature parity, output set) repeats with this period
 

@@ -70,6 +70,9 @@ typedef struct HpeConfig {
     int mesh_a2b;          /* HPE_MESH_A2B         pixel -> vertex search of the mesh loss: 0 cell grid (default), 1 VALU full
                             *                      search, 2 matrix-core full search */
     int wino_f4;           /* HPE_WINO_F4          3x3 layers on the 56x56 / 28x28 maps as Winograd F(4x4,3x3) */
+    int bf16_p8;           /* HPE_BF16_P8          bf16 layer kinds on the 256 x 256 phase-interleaved GEMM kernel (N % 256 == 0, K >= 512 only):
+                            *                      1 the 3x3 layers of stage 4, 2 those of stage 5, 4 1x1 / strided layers, 8 the dual-source
+                            *                      launch of res5a, 16 the other dual-source launches */
 } HpeConfig;
 
 /* defaults: device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1 */
@@ -210,7 +213,8 @@ int hpe_get_original(const float* verts_dev, const float* cam_dev, int B, int P,
 /* -- test / measurement hooks -------------------------------------------------------------------- */
 /* Run loaded conv layer `idx` (+BN, optional residual, optional ReLU) on x_dev [B,Hin,Hin,Cin] ->
  * y_dev [B,Hout,Hout,Cout]; for idx 0 the input is the raw [B,224,224,3] image and y is the
- * post-ReLU conv1 output [B,112,112,64]. */
+ * post-ReLU conv1 output [B,112,112,64].  On a bf16 context (idx > 0 only) x / residual are rounded to bf16 on the way in, the
+ * layer runs through the bf16 kernel the plan picks for this batch, and y is its bf16 output widened to float. */
 int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float* residual_dev, int relu, float* y_dev,
                    void* stream);
 /* The fused stem kernel alone (conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + MaxPooling2D(3,2) of the Keras ResNet50,

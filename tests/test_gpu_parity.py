@@ -792,6 +792,85 @@ def test_bf16_encoder_variant(assets):
     eng.close()
 
 
+# ------------------------------------------------------------------------------------------- bf16 256 x 256 phase-interleaved kernel
+def _bf16_round(x):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.fixture(scope="module")
+def engines_bf16_old_and_p8(assets):
+    """Two bf16 encoder contexts side by side: the round-2 kernels everywhere (bf16_p8=0) and every eligible layer on the 256 x 256
+    phase-interleaved kernel (bf16_p8=31: 3x3, 1x1 / strided and dual-source launches with N % 256 == 0 and K >= 512)."""
+    made = [encoder_engine(assets, 256, encoder_dtype="bf16", bf16_p8=0), encoder_engine(assets, 256, encoder_dtype="bf16", bf16_p8=31)]
+    yield made
+    for e in made:
+        e.close()
+
+
+P8_CASES = ["res4b_branch2b", "res5b_branch2b", "res5b_branch2a", "res4a_branch2a", "res5a_branch2a", "res4c_branch2a"]
+
+
+@pytest.mark.parametrize("name", P8_CASES)
+@pytest.mark.parametrize("B", [3, 37])
+def test_bf16_p8_layer_matches_oracle(engines_bf16_old_and_p8, assets, name, B):
+    """One layer through conv_gemm_bf16_p8_kernel (256 x 256 tile, split-K + fix-up at these small grids, masked last row tile:
+    M = 147 ... 7252 is never a multiple of 256) against the fp64 convolution of the same bf16-rounded operands, and against the
+    round-2 kernel: the two differ by fp32 summation order only, i.e. by at most one bf16 ulp of the output."""
+    old, new = engines_bf16_old_and_p8
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    g = np.random.Generator(np.random.Philox(1500 + idx + B))
+    x = g.normal(0, 1, (B, s.hin, s.hin, s.cin)).astype(np.float32)
+    x[g.random(x.shape) < 0.3] = 0.0
+    x[0, 0, 0, :] = 20.0  # a corner pixel (only 4 of the 9 taps of a 3x3 layer see it)
+    xb = _bf16_round(x)
+    y_new = cpu(new.debug_conv(idx, gpu(x), relu=True))
+    y_old = cpu(old.debug_conv(idx, gpu(x), relu=True))
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    pad = 1 if s.kh == 3 else 0
+    lin = O.conv2d_nhwc(xb, _bf16_round(p[s.name + "/kernel"]), p[s.name + "/bias"], s.stride, pad, dtype=np.float64) * sc + sh
+    ref = np.maximum(lin, 0)
+    assert y_new.shape == ref.shape
+    ulp = 2.0 ** -8
+    assert rel(y_new, ref) < ulp and rel(y_old, ref) < ulp, (rel(y_new, ref), rel(y_old, ref))
+    assert float(np.linalg.norm(y_new - ref) / np.linalg.norm(ref)) < 2.5e-3
+    assert rel(y_new, y_old) < ulp
+
+
+@pytest.mark.parametrize("name", ["res4c_branch2b", "res5a_branch2a", "res5c_branch2b"])
+def test_bf16_p8_full_size_layer_equals_round2_kernel(engines_bf16_old_and_p8, name):
+    """The metric batch (256 images): 196 / 392 tiles run unsplit, the 98 tiles of stage 5 split K three ways.  The oracle is too
+    slow here; the round-2 kernel (oracle-checked above and in the encoder tests) is the comparison."""
+    old, new = engines_bf16_old_and_p8
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    g = np.random.Generator(np.random.Philox(1700 + idx))
+    x = gpu(np.maximum(g.normal(0, 1, (256, s.hin, s.hin, s.cin)), 0).astype(np.float32))
+    y_new = cpu(new.debug_conv(idx, x, relu=True))
+    y_old = cpu(old.debug_conv(idx, x, relu=True))
+    assert rel(y_new, y_old) < 2.0 ** -8
+    assert float(np.linalg.norm(y_new - y_old) / np.linalg.norm(y_old)) < 1e-3
+
+
+def test_bf16_p8_encoder_matches_round2_encoder(engines_bf16_old_and_p8, assets):
+    """Whole bf16 encoder with the eligible layers (stage 4 / 5 3x3 and 1x1, the dual-source conv_block launches) on the new kernel:
+    features within the bf16 tolerance of the round-2 encoder and of the rounding-point-emulating oracle, at a chunked batch too."""
+    old, new = engines_bf16_old_and_p8
+    img = gpu(synthetic.make_images(5, seed=81))
+    fo, fn = cpu(old.encoder(img)).astype(np.float64), cpu(new.encoder(img)).astype(np.float64)
+    l2 = float(np.linalg.norm(fn - fo) / np.linalg.norm(fo))
+    print("bf16 p8 encoder vs round-2 kernels: rel-L2 %.3g" % l2)
+    assert l2 < 3e-3
+    ref = O.resnet50_features(cpu(img[:2]), assets["enc"])
+    assert float(np.linalg.norm(fn[:2] - ref) / np.linalg.norm(ref)) < 1e-2
+    big = gpu(synthetic.make_images(100, seed=82))  # two concurrent chunks of 50
+    fo, fn = cpu(old.encoder(big)).astype(np.float64), cpu(new.encoder(big)).astype(np.float64)
+    assert float(np.linalg.norm(fn - fo) / np.linalg.norm(fo)) < 3e-3
+
+
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
 @pytest.mark.parametrize("variant", ["survey", "bounded"])
 @pytest.mark.parametrize("B", [64, 256])
