@@ -1,0 +1,332 @@
+// conv_wino4.hip -- 3x3 / stride 1 / SAME convolutions (res*_branch2b; reference: src/models.py:39 -> keras_applications resnet50
+// conv_block / identity_block) as Winograd F(4x4, 3x3) in fp32 (round 3):
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 4x4 output tile (6x6 input tile), summed over input channels
+//
+// 36 multiplies per 16 outputs and channel pair: 4x fewer than the direct convolution, 1.78x fewer than the F(2x2, 3x3) of
+// conv_wino.hip (on the 7x7 maps both cover 8x8, on the 14x14 maps this one covers 16x16: 1.36x there).  The transformed input
+// is also SMALLER than F(2x2)'s (36 components per 16 pixels = 2.25 floats per input float instead of 4), so the blocked-V round
+// trip through HBM that F(2x2) could only afford on the small maps is the cheap part here.  Arithmetic is fp32 end to end, U in
+// double on the host.  Error against the fp64 convolution: max 1e-5 of the layer's largest output (F(2x2) / direct: 1.5e-6); it
+// does not accumulate through the network -- features, vertices and keypoints stay where they were (tests).
+//
+//     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]           (Lavin & Gray, interpolation points 0, +-1, +-2)
+//
+//   w4_input_kernel   x [B,H,W,C] NHWC -> V, HBM bound.  V is stored in the byte image of the GEMM's LDS staging:
+//                     V[tile block of 32][slab of 4 ch][comp 36][tile 32][4 ch]  (a k-slab of a workgroup = 18 KB contiguous)
+//   w4_gemm_kernel    36 independent GEMMs M_c[tile][cout] = sum_ch V_c[tile][ch] * U_c[cout][ch] for a 32-tile x 64-cout block, all
+//                     36 components in one workgroup of 12 waves: wave (xi, nb) owns row xi of the 6x6 component grid for cout
+//                     half nb = six 32x32 MFMA blocks = 96 accumulator VGPRs.  LDS-DMA double buffering of 54-KB slabs (V 18 KB +
+//                     U 36 KB), two slabs in flight with the barrier in the middle of a slab's MFMA work (as wino_gemm_kernel).
+//                     Output transform: the wave applies (.) A to its own row in registers (6 -> 4 values), the rows meet in LDS
+//                     for A^T (.), then BN scale/shift, ReLU and 16-B NHWC stores.
+#include "hpe_internal.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int W4_T = 32;                      // tiles per workgroup
+constexpr int W4_N = 64;                      // output channels per workgroup
+constexpr int W4_VS = 36 * W4_T * 4;          // floats of a V slab (4 channels): 4608 = 18 KB
+constexpr int W4_US = 36 * W4_N * 4;          // floats of a U slab: 9216 = 36 KB
+constexpr int W4_SLAB = W4_VS + W4_US;        // 13824 floats = 54 KB
+constexpr int W4_LDS_BYTES = 2 * W4_SLAB * (int)sizeof(float);  // 108 KB (the epilogue's 96-KB exchange area reuses it)
+constexpr int W4_THREADS = 768;
+constexpr int W4_DMA = W4_SLAB / 256;         // 54 wave-instructions of 1 KB per slab
+
+// row transform of B^T (used for rows, then for columns)
+#define W4_BT(o0, o1, o2, o3, o4, o5, d0, d1, d2, d3, d4, d5) \
+    do {                                                       \
+        o0 = 4.f * (d0) - 5.f * (d2) + (d4);                   \
+        o1 = (d3) + (d4) - 4.f * ((d1) + (d2));                \
+        o2 = 4.f * ((d1) - (d2)) - (d3) + (d4);                \
+        o3 = 2.f * ((d3) - (d1)) - (d2) + (d4);                \
+        o4 = 2.f * ((d1) - (d3)) - (d2) + (d4);                \
+        o5 = 4.f * (d1) - 5.f * (d3) + (d5);                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ input transform
+// one thread = (tile, 4 channels); a wave = 8 tiles x 32 channels: full 128-B lines on the read side, 128-B segments on the write side
+__global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, int TW, int TT,
+                                                       int T, int Tpad, int lda) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = gid & 63;
+    const int wv = gid >> 6;
+    const int ncb = C >> 5;
+    const int tg = wv / ncb;
+    const int cb = wv - tg * ncb;
+    const int t = tg * 8 + (lane >> 3);
+    if (t >= Tpad) return;
+    const int c = cb * 32 + (lane & 7) * 4;
+    const int S = C >> 2;
+    float* dst = V + ((size_t)(t >> 5) * S + (c >> 2)) * W4_VS + (t & 31) * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (t >= T) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) *reinterpret_cast<f32x4*>(dst + k * (W4_T * 4)) = z;
+        return;
+    }
+    const int b = t / TT;
+    const int rem = t - b * TT;
+    const int ty = rem / TW;
+    const int tx = rem - ty * TW;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    f32x4 r[6][6];  // r[xi][e] = (B^T d)[xi][e]
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int ix = x0 + e;
+        const bool okx = ix >= 0 && ix < W;
+        f32x4 d[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const int iy = y0 + a;
+            const bool ok = okx && iy >= 0 && iy < H;
+            d[a] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * lda + c) : z;
+        }
+        W4_BT(r[0][e], r[1][e], r[2][e], r[3][e], r[4][e], r[5][e], d[0], d[1], d[2], d[3], d[4], d[5]);
+    }
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+        f32x4 o[6];
+        W4_BT(o[0], o[1], o[2], o[3], o[4], o[5], r[xi][0], r[xi][1], r[xi][2], r[xi][3], r[xi][4], r[xi][5]);
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x4*>(dst + (xi * 6 + nu) * (W4_T * 4)) = o[nu];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 36-component GEMM + output transform
+struct W4Args {
+    const float* V;
+    const float* U;
+    const float* scale;
+    const float* shift;
+    float* y;
+    int H, W, N;     // output map, output channels
+    int TW, TT, T;   // tiles per row / per image / total
+    int S;           // k-slabs (C / 4)
+    int n_tb, n_nt;  // tile blocks, cout blocks
+    int ldy, relu;
+};
+
+__global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 slabs; reused by the epilogue
+
+    const int total = p.n_tb * p.n_nt;
+    const int bid = blockIdx.x;
+    // XCD-aware bijective remap: consecutive logical ids (the cout blocks of one tile block) share an XCD and its L2
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tb = lid / p.n_nt;
+    const int nt = lid - tb * p.n_nt;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int xi = wave >> 1;  // component row owned by this wave
+    const int nb = wave & 1;   // cout half (32 couts)
+    const int hi = lane >> 5;
+
+    const float* vsrc = p.V + (size_t)tb * p.S * W4_VS + lane * 4;
+    const float* usrc = p.U + (size_t)nt * p.S * W4_US + lane * 4;
+
+    // slab s -> buffer buf: 54 wave-instructions of 1 KB, instruction k = wave + 12 i (V for k < 18, U after)
+    auto issue = [&](int s, int buf) {
+        const float* sv = vsrc + (size_t)s * W4_VS;
+        const float* su = usrc + (size_t)s * W4_US;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = wave + 12 * i;
+            if (k < W4_DMA) {
+                const float* src = (k < 18) ? sv + k * 256 : su + (k - 18) * 256;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds + buf * W4_SLAB + k * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+
+    // fragment offsets (floats): V [comp][tile 32][4], U [comp][cout 64][4]; lanes 0-31 take channels 0-1, lanes 32-63 channels 2-3
+    const int fv = (xi * 6) * (W4_T * 4) + (lane & 31) * 4 + 2 * hi;
+    const int fu = W4_VS + (xi * 6) * (W4_N * 4) + (32 * nb + (lane & 31)) * 4 + 2 * hi;
+    const int S = p.S;
+
+    // Two slabs in flight.  Per slab s: [fragment reads, MFMAs of components 0-2] [barrier] [DMA of slab s+2 into the buffer slab s has
+    // just vacated] [MFMAs of components 3-5]: the barrier comes after this wave has pulled ALL its fragments of slab s into registers,
+    // so the buffer is free for slab s+2, and that DMA has a whole slab of MFMA time to land before barrier s+1 waits for it.
+    issue(0, 0);
+    if (S > 1) issue(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (once per workgroup: not worth a per-wave counted wait)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < S; ++s) {
+        const int cur = (s & 1) * W4_SLAB;
+        f32x2 fa[6], fb[6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) {
+            fa[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fv + nu * (W4_T * 4)]);
+            fb[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fu + nu * (W4_N * 4)]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0): my fragments of slab s are in registers; vmcnt(0): my part of slab s+1 has landed.  Written out: with the
+        // wave-uniform branches of issue() in the loop hipcc's __syncthreads() emitted only the lgkmcnt wait here (found as whole
+        // tile blocks that came out wrong, now and then, once >= 200 workgroups stretched the DMA latency)
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < S) issue(s + 2, s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nu = 3; nu < 6; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();  // all waves out of the last slab before the epilogue reuses the LDS
+
+    // ---- output transform.  (.) A in registers: P[j] = sum_nu A^T[j][nu] M[xi][nu]
+    f32x16 P[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e], a4 = acc[4][e], a5 = acc[5][e];
+        const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+        P[0][e] = a0 + s12 + s34;
+        P[1][e] = d12 + 2.f * d34;
+        P[2][e] = s12 + 4.f * s34;
+        P[3][e] = d12 + 8.f * d34 + a5;
+    }
+    // A^T (.) across the six waves of a cout half, through LDS, two output columns per pass:
+    //   exchange area [xi 6][jj 2][tile 32][cout 64] floats = 96 KB
+    const int em = t >> 4;        // gather role (threads 0 .. 511): tile within the block
+    const int eq = (t & 15) * 4;  // cout quad
+    const int n = nt * W4_N + eq;
+    const bool gather = t < 512;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    int b = 0, ty = 0, tx = 0;
+    bool live = false;
+    if (gather) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        const int tg = tb * W4_T + em;
+        live = tg < p.T;
+        if (live) {
+            b = tg / p.TT;
+            const int rem = tg - b * p.TT;
+            ty = rem / p.TW;
+            tx = rem - ty * p.TW;
+        }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        if (jp) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                lds[((xi * 2 + jj) * W4_T + m) * W4_N + 32 * nb + (lane & 31)] = P[2 * jp + jj][e];
+            }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 Q[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Q[k] = *reinterpret_cast<const f32x4*>(&lds[((k * 2 + jj) * W4_T + em) * W4_N + eq]);
+                const f32x4 s12 = Q[1] + Q[2], d12 = Q[1] - Q[2], s34 = Q[3] + Q[4], d34 = Q[3] - Q[4];
+                f32x4 o[4];
+                o[0] = Q[0] + s12 + s34;
+                o[1] = d12 + 2.f * d34;
+                o[2] = s12 + 4.f * s34;
+                o[3] = d12 + 8.f * d34 + Q[5];
+                const int ox = 4 * tx + 2 * jp + jj;
+                if (ox < p.W) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int oy = 4 * ty + i;
+                        if (oy < p.H) {
+                            f32x4 v = o[i] * sc + sh;
+                            if (p.relu) {
+                                v.x = fmaxf(v.x, 0.f);
+                                v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f);
+                                v.w = fmaxf(v.w, 0.f);
+                            }
+                            *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// hipFuncSetAttribute applies to the CURRENT device: hpe_finalize calls this once per ctx under its device guard
+hipError_t hpe_wino4_init_device() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(w4_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+}
+
+size_t hpe_wino4_v_floats(int B, int H, int W, int C) {
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+    const size_t T = (size_t)B * TH * TW;
+    return ((T + W4_T - 1) / W4_T) * W4_T * 36 * (size_t)C;
+}
+
+int hpe_wino4_items(int B, int H, int W, int N) {
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4;
+    return (int)(((long)B * TH * TW + W4_T - 1) / W4_T) * (N / W4_N);
+}
+
+hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
+                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st) {
+    if (C % 32 != 0 || N % 64 != 0 || lda % 4 != 0 || ldy % 4 != 0 || B < 1 || H < 1 || W < 1 || !x || !U || !V || !y) return hipErrorInvalidValue;
+    const int TH = (H + 3) / 4, TW = (W + 3) / 4, TT = TH * TW;
+    const long Tl = (long)B * TT;
+    if (Tl > (1L << 30)) return hipErrorInvalidValue;
+    const int T = (int)Tl;
+    const int Tpad = (T + W4_T - 1) / W4_T * W4_T;
+    {
+        const long waves = (long)(Tpad / 8) * (C / 32);
+        const int blocks = (int)((waves + 3) / 4);
+        hipLaunchKernelGGL(w4_input_kernel, dim3(blocks), dim3(256), 0, st, x, V, H, W, C, TW, TT, T, Tpad, lda);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    W4Args p{};
+    p.V = V;
+    p.U = U;
+    p.scale = scale;
+    p.shift = shift;
+    p.y = y;
+    p.H = H;
+    p.W = W;
+    p.N = N;
+    p.TW = TW;
+    p.TT = TT;
+    p.T = T;
+    p.S = C / 4;
+    p.n_tb = Tpad / W4_T;
+    p.n_nt = N / W4_N;
+    p.ldy = ldy;
+    p.relu = relu;
+    hipLaunchKernelGGL(w4_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(W4_THREADS), W4_LDS_BYTES, st, p);
+    return hipGetLastError();
+}

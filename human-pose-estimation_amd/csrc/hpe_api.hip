@@ -94,6 +94,7 @@ struct ConvLayer {
     int k_dual = 0, k1_dual = 0;
     void* stem_w = nullptr;   // conv1 only: weights in the k enumeration of stem_fused.hip (fp32 [64][160] / bf16 [64][7][32])
     float* wino_u = nullptr;  // device, G g G^T in the blocked layout of conv_wino.hip (3x3 layers on the Winograd path only)
+    float* wino4_u = nullptr;  // device, the F(4x4,3x3) G g G^T in the blocked layout of conv_wino4.hip (layers selected by wino_f4)
     int n_pad = 0, k_pad = 0;
 };
 
@@ -178,6 +179,7 @@ struct hpe_ctx {
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
+    int wino_f4 = 0;          // map sizes whose 3x3 layers run as Winograd F(4x4,3x3): bit 0: 7x7, 1: 14x14, 2: 28x28, 3: 56x56 (HPE_WINO_F4)
     int mesh_a2b = 0;         // pixel -> vertex search of the mesh loss: 0 cell grid, 1 VALU full search, 2 matrix-core full search
     bool loss_attr_done = false;  // per-device kernel attributes of the loss kernels set (hpe_finalize, or the first loss call of a loss-only ctx)
     unsigned long long* loss_counter = nullptr;  // hpe_debug_set_loss_counter
@@ -301,9 +303,18 @@ Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expan
 
 // one conv layer (+BN fold, +residual, +ReLU) through the implicit-GEMM kernel
 
+inline int f4_bit(int hin) { return hin <= 7 ? 1 : (hin <= 14 ? 2 : (hin <= 28 ? 4 : 8)); }
+
+// the 3x3 layer idx runs as Winograd F(4x4,3x3) for this batch (blocked V through the workspace)
+bool use_wino4(const hpe_ctx* c, int idx, int B) {
+    const ConvSpec& s = specs()[idx];
+    return !c->bf16 && c->conv[idx].wino4_u && s.kh == 3 && s.stride == 1 && hpe_wino4_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
+}
+
 // the 3x3 layer idx runs as the fused Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
 bool use_wino_fused(const hpe_ctx* c, int idx, int B) {
     const ConvSpec& s = specs()[idx];
+    if (use_wino4(c, idx, B)) return false;
     return c->wino_fused && !c->bf16 && c->conv[idx].wino_u && s.kh == 3 && s.stride == 1 && s.hin >= c->wino_fused_min_hw &&
            hpe_wino_fused_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
 }
@@ -316,6 +327,8 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     const ConvLayer& L = c->conv[idx];
     if (flags & CONV_IN_SLAB8)
         return hpe_launch_wino_fused_conv3(x, L.wino_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
+    if (wino_v && !res && use_wino4(c, idx, B))
+        return hpe_launch_wino4_conv3(x, s.cin, L.wino4_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st);
     // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
     // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
     if (L.wino_u && wino_v && !res && s.cin >= c->wino_min_c &&
@@ -806,6 +819,7 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_fused_min_hw = opt(c->cfg.wino_fused_min_hw, "HPE_WINO_FUSED_MINHW", 28);
         c->stem_fused = opt(c->cfg.stem_fused, "HPE_STEM_FUSED", 1);
         c->dual_gemm = opt(c->cfg.dual_gemm, "HPE_DUAL", 1);
+        c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 0) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
         c->knobs.concurrent_tiles = e ? atoi(e) : 0;
@@ -834,6 +848,7 @@ static int finalize_impl(hpe_ctx* c) {
         if (e) c->knobs.bf16_p8_min_k = atoi(e);
         // per-device function attributes (dynamic LDS above 64 KB) of the Winograd and stem kernels
         HIP_TRY(hpe_wino_init_device());
+        HIP_TRY(hpe_wino4_init_device());
         HIP_TRY(hpe_stem_fused_init_device());
         HIP_TRY(hpe_losses_init_device());
         c->mesh_a2b = c->cfg.mesh_a2b >= 0 ? c->cfg.mesh_a2b : hpe_mesh_a2b_mode_from_env();
@@ -935,6 +950,29 @@ static int finalize_impl(hpe_ctx* c) {
                         }
                 }
             if ((rc = upload(c, &L.wino_u, U))) return rc;
+        }
+        if (c->wino_f4 && s.kh == 3 && s.stride == 1 && s.cin % 32 == 0 && s.cout % 64 == 0 && (c->wino_f4 & f4_bit(s.hin))) {
+            // F(4x4,3x3): U = G g G^T with G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], in double;
+            // layout [cout/64][cin/4][36][64][4]
+            static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            const int S4 = s.cin / 4;
+            std::vector<float> U((size_t)36 * s.cin * s.cout);
+            for (int ci = 0; ci < s.cin; ++ci)
+                for (int n = 0; n < s.cout; ++n) {
+                    double g[3][3];
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) g[a][b] = L.kernel[(((size_t)a * 3 + b) * s.cin + ci) * s.cout + n];
+                    const size_t base = (((size_t)(n >> 6) * S4 + (ci >> 2)) * 36) * 256 + (size_t)(n & 63) * 4 + (ci & 3);
+                    for (int xi = 0; xi < 6; ++xi)
+                        for (int nu = 0; nu < 6; ++nu) {
+                            double u = 0.0;
+                            for (int a = 0; a < 3; ++a)
+                                for (int b = 0; b < 3; ++b) u += G4[xi][a] * G4[nu][b] * g[a][b];
+                            U[base + (size_t)(xi * 6 + nu) * 256] = (float)u;
+                        }
+                }
+            if ((rc = upload(c, &L.wino4_u, U))) return rc;
         }
         }
         if (i == 0) {  // fused stem: same weights in the k enumeration of stem_fused.hip

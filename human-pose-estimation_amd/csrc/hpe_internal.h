@@ -58,6 +58,14 @@ hipError_t hpe_launch_wino_fused_conv3(const float* xs, const float* U, const fl
 int hpe_wino_fused_items(int B, int H, int W, int N);  // work items of that launch, 0 if the geometry is not supported
 hipError_t hpe_launch_nhwc_to_slab8(const float* x, float* xs, long M, int C, hipStream_t st);
 
+// conv_wino4.hip: the same convolution as Winograd F(4x4,3x3); U = G g G^T blocked [N/64][C/4][36][64][4], V workspace of
+// hpe_wino4_v_floats(B, H, W, C) floats (blocked [tiles/32][C/4][36][32][4]); C % 32 == 0, N % 64 == 0
+size_t hpe_wino4_v_floats(int B, int H, int W, int C);
+int hpe_wino4_items(int B, int H, int W, int N);  // workgroups of the GEMM launch
+hipError_t hpe_wino4_init_device();
+hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
+                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st);
+
 // conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ring_depth, hipStream_t st);  // ring_depth 2..4 LDS slab buffers
 // conv_gemm_bf16_p8.hip: 256 x 256 x 64 tile, 8 waves, phase-interleaved main loop, split-K through p.partial (DENSE / STRIDED / CONV3 / DUAL)

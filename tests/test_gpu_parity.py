@@ -220,6 +220,85 @@ def test_winograd_conv_matches_oracle_and_direct(engines_direct_and_wino, assets
     assert rel(cpu(wino.debug_conv(idx, gpu(x), relu=False)), lin) < 5e-6
 
 
+# ------------------------------------------------------------------------------------------- Winograd F(4x4,3x3)
+@pytest.fixture(scope="module")
+def engine_wino4(assets):
+    """Encoder-only context whose 3x3 layers on every map size run as Winograd F(4x4,3x3) at any batch (wino_f4=15, wino_min_items=0)."""
+    e = encoder_engine(assets, 40, wino_f4=15, wino_min_items=0)
+    yield e
+    e.close()
+
+
+W4_CASES = ["res2b_branch2b", "res3a_branch2b", "res3d_branch2b", "res4c_branch2b", "res5a_branch2b", "res5c_branch2b"]
+
+
+@pytest.mark.parametrize("name", W4_CASES)
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_winograd4_conv_matches_oracle(engine_wino4, engines_direct_and_wino, assets, name, B):
+    """F(4x4,3x3) against the fp64 oracle convolution: 56 / 28 maps tile exactly (14 / 7 tiles per side), the 14x14 and 7x7 maps
+    use a 4x4 / 2x2 tile grid with masked rows and columns; B = 37 gives tile counts that are not a multiple of the 32-tile
+    workgroup block (zero tiles, masked stores).  Input includes exact zeros and a large corner value.
+    Tolerance: the 6x6 transforms (entries up to 8, 1/24) cost about one decimal digit against the direct kernel -- max error
+    <= 5e-5 of the layer's largest output (measured 3e-6 ... 3.5e-5 with the 50.0 corner pixel in; direct / F(2x2): <= 5e-6) and rel-L2 <= 2e-5 (measured <= 9e-6)."""
+    direct = engines_direct_and_wino[0]
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    if B == 37 and s.hin > 28:
+        pytest.skip("oracle conv at this size is slow; covered by B = 3")
+    g = np.random.Generator(np.random.Philox(2500 + idx + B))
+    x = g.normal(0, 1, (B, s.hin, s.hin, s.cin)).astype(np.float32)
+    x[g.random(x.shape) < 0.3] = 0.0  # post-ReLU sparsity
+    x[0, 0, 0, :] = 50.0  # a corner pixel: only 4 of the 9 taps see it
+    yw = cpu(engine_wino4.debug_conv(idx, gpu(x), relu=True))
+    yd = cpu(direct.debug_conv(idx, gpu(x), relu=True))
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    lin = O.conv2d_nhwc(x, p[s.name + "/kernel"], p[s.name + "/bias"], 1, 1, dtype=np.float64) * sc + sh
+    ref = np.maximum(lin, 0)
+    assert yw.shape == ref.shape
+    l2 = float(np.linalg.norm(yw - ref) / np.linalg.norm(ref))
+    print("%s B=%d  F(4x4): max rel %.3g, rel-L2 %.3g   direct: max rel %.3g" % (name, B, rel(yw, ref), l2, rel(yd, ref)))
+    assert rel(yw, ref) < 5e-5 and l2 < 2e-5, (rel(yw, ref), l2)
+    assert rel(cpu(engine_wino4.debug_conv(idx, gpu(x), relu=False)), lin) < 5e-5  # negative side preserved
+
+
+def test_winograd4_encoder_features(engine_wino4, engines_direct_and_wino, assets):
+    """Whole encoder with all sixteen 3x3 layers as F(4x4,3x3): the per-layer error does not accumulate -- features stay within
+    fp32 round-off of the all-direct context and of the oracle."""
+    direct = engines_direct_and_wino[0]
+    img = synthetic.make_images(5, seed=177)
+    fd, fw = cpu(direct.encoder(gpu(img))), cpu(engine_wino4.encoder(gpu(img)))
+    ref = O.resnet50_features(img, assets["enc"], dtype=np.float64)
+    print("features vs fp64 oracle: F(4x4) %.3g, direct %.3g" % (rel(fw, ref), rel(fd, ref)))
+    assert rel(fw, fd) < 2e-5
+    assert rel(fw, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,streams", [(100, 1), (256, 2)])
+def test_winograd4_full_size_equals_direct(assets, B, streams):
+    """Metric-size launches (200 ... 512 workgroups of the F(4x4) GEMM in flight, one or two chunk streams): features and two layers
+    equal the all-direct context's.  This is the test that catches a staging race -- the first version of w4_gemm_kernel lost its
+    vmcnt wait in front of the mid-slab barrier and produced whole wrong tile blocks only from ~200 workgroups on."""
+    img = gpu(synthetic.make_images(B, seed=9))
+    base = encoder_engine(assets, B, wino_min_c=0, n_streams=1)
+    f0 = cpu(base.encoder(img))
+    e = encoder_engine(assets, B, wino_f4=3, n_streams=streams)
+    for _ in range(3):
+        f = cpu(e.encoder(img))
+        bad = np.where(np.abs(f - f0).max(1) / np.abs(f0).max() > 2e-5)[0]
+        assert bad.size == 0, bad[:16]
+    for name in ("res4b_branch2b", "res5b_branch2b"):
+        idx = resnet_spec.CONV_INDEX[name]
+        s = resnet_spec.CONV_SPECS[idx]
+        g = np.random.Generator(np.random.Philox(idx))
+        x = gpu(np.maximum(g.normal(0, 1, (B, s.hin, s.hin, s.cin)), 0).astype(np.float32))
+        yd, yw = cpu(base.debug_conv(idx, x)), cpu(e.debug_conv(idx, x))
+        err = np.abs(yw - yd).reshape(B, -1).max(1) / np.abs(yd).max()
+        assert float(err.max()) < 5e-5, (name, np.where(err > 5e-5)[0][:16])
+    base.close()
+    e.close()
+
+
 def test_winograd_encoder_features_match_direct(engines_direct_and_wino, assets):
     """Whole encoder, 40 images (2 batch chunks would need >= 64): features of the two contexts agree to fp32 round-off and
     both match the oracle."""
