@@ -22,6 +22,8 @@
 //                     U 36 KB), two slabs in flight with the barrier in the middle of a slab's MFMA work (as wino_gemm_kernel).
 //                     Output transform: the wave applies (.) A to its own row in registers (6 -> 4 values), the rows meet in LDS
 //                     for A^T (.), then BN scale/shift, ReLU and 16-B NHWC stores.
+#include <stdlib.h>
+
 #include "hpe_internal.h"
 
 namespace {
@@ -113,6 +115,8 @@ struct W4Args {
     int ldy, relu;
 };
 
+// ABL (diagnostics builds, -DHPE_ABLATION + HPE_W4_ABL; results wrong): 1 = no V DMA, 2 = no U DMA, 4 = no MFMAs, 8 = no fragment reads
+template <int ABL>
 __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 slabs; reused by the epilogue
 
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int k = wave + 12 * i;
-            if (k < W4_DMA) {
+            if (k < W4_DMA && !((ABL & 1) && k < 18) && !((ABL & 2) && k >= 18)) {
                 const float* src = (k < 18) ? sv + k * 256 : su + (k - 18) * 256;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lds + buf * W4_SLAB + k * 256), 16, 0, 0);
@@ -173,15 +177,22 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
     for (int s = 0; s < S; ++s) {
         const int cur = (s & 1) * W4_SLAB;
         f32x2 fa[6], fb[6];
+        if (!(ABL & 8)) {
 #pragma unroll
-        for (int nu = 0; nu < 6; ++nu) {
-            fa[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fv + nu * (W4_T * 4)]);
-            fb[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fu + nu * (W4_N * 4)]);
+            for (int nu = 0; nu < 6; ++nu) {
+                fa[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fv + nu * (W4_T * 4)]);
+                fb[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fu + nu * (W4_N * 4)]);
+            }
+        } else {
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) fa[nu] = fb[nu] = f32x2{1.f, 1.f};
         }
+        if (!(ABL & 4)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nu = 0; nu < 3; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // lgkmcnt(0): my fragments of slab s are in registers; vmcnt(0): my part of slab s+1 has landed.  Written out: with the
         // wave-uniform branches of issue() in the loop hipcc's __syncthreads() emitted only the lgkmcnt wait here (found as whole
@@ -192,10 +203,15 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
         asm volatile("" ::: "memory");
         if (s + 2 < S) issue(s + 2, s & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 4)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nu = 3; nu < 6; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) acc[nu][0] += fa[nu][0] * fb[nu][1];
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();  // all waves out of the last slab before the epilogue reuses the LDS
@@ -281,7 +297,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
 
 // hipFuncSetAttribute applies to the CURRENT device: hpe_finalize calls this once per ctx under its device guard
 hipError_t hpe_wino4_init_device() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(w4_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+#ifdef HPE_ABLATION
+    for (const void* f : {(const void*)w4_gemm_kernel<1>, (const void*)w4_gemm_kernel<2>, (const void*)w4_gemm_kernel<3>, (const void*)w4_gemm_kernel<4>,
+                          (const void*)w4_gemm_kernel<8>, (const void*)w4_gemm_kernel<12>})
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+#endif
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(w4_gemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
 }
 
 size_t hpe_wino4_v_floats(int B, int H, int W, int C) {
@@ -327,6 +348,22 @@ hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const
     p.n_nt = N / W4_N;
     p.ldy = ldy;
     p.relu = relu;
-    hipLaunchKernelGGL(w4_gemm_kernel, dim3(p.n_tb * p.n_nt), dim3(W4_THREADS), W4_LDS_BYTES, st, p);
+#ifdef HPE_ABLATION
+    static const int abl = [] {
+        const char* e = getenv("HPE_W4_ABL");
+        return e ? atoi(e) : 0;
+    }();
+    const dim3 g(p.n_tb * p.n_nt), b(W4_THREADS);
+    switch (abl) {
+        case 1: hipLaunchKernelGGL(w4_gemm_kernel<1>, g, b, W4_LDS_BYTES, st, p); return hipGetLastError();
+        case 2: hipLaunchKernelGGL(w4_gemm_kernel<2>, g, b, W4_LDS_BYTES, st, p); return hipGetLastError();
+        case 3: hipLaunchKernelGGL(w4_gemm_kernel<3>, g, b, W4_LDS_BYTES, st, p); return hipGetLastError();
+        case 4: hipLaunchKernelGGL(w4_gemm_kernel<4>, g, b, W4_LDS_BYTES, st, p); return hipGetLastError();
+        case 8: hipLaunchKernelGGL(w4_gemm_kernel<8>, g, b, W4_LDS_BYTES, st, p); return hipGetLastError();
+        case 12: hipLaunchKernelGGL(w4_gemm_kernel<12>, g, b, W4_LDS_BYTES, st, p); return hipGetLastError();
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL(w4_gemm_kernel<0>, dim3(p.n_tb * p.n_nt), dim3(W4_THREADS), W4_LDS_BYTES, st, p);
     return hipGetLastError();
 }

@@ -819,7 +819,9 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_fused_min_hw = opt(c->cfg.wino_fused_min_hw, "HPE_WINO_FUSED_MINHW", 28);
         c->stem_fused = opt(c->cfg.stem_fused, "HPE_STEM_FUSED", 1);
         c->dual_gemm = opt(c->cfg.dual_gemm, "HPE_DUAL", 1);
-        c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 0) : 0;
+        // F(4x4,3x3) on the 28x28 / 14x14 / 7x7 maps by default (A/B on one box: 17,720 -> 18,790 img/s; with the 7x7 and 14x14 maps only
+        // 18,540; the 56x56 maps lose: their V round trip costs more than the direct kernel's extra multiplies)
+        c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
         c->knobs.concurrent_tiles = e ? atoi(e) : 0;

@@ -36,7 +36,7 @@ def _require_cuda_tensor(t, name, shape_tail=None):
 class HpeEngine(object):
     def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3, encoder_dtype="fp32", **plan_options):
         """plan_options: the HpeConfig plan fields of include/hpe.h (n_streams, dual_gemm, stem_fused, wino_min_c, wino_min_items,
-        wino_fused, wino_fused_min_hw, mesh_a2b, wino_f4); unset = -1 = the library default (environment variable, else built-in).
+        wino_fused, wino_fused_min_hw, mesh_a2b, wino_f4, bf16_p8); unset = -1 = the library default (environment variable, else built-in).
         They select WHICH kernels run, per context -- two engines with different options can coexist in one process."""
         self.lib = _lib.load()
         torch = _torch()
@@ -467,8 +467,9 @@ class HpeEngine(object):
     def encoder_kernel_description(self):
         """The kernel family bench.py's `roofline` block prices (one string per encoder dtype, kept next to the dispatch)."""
         if self.encoder_dtype == "fp32":
-            return ("conv_gemm_f32_dma_kernel (37 layers) + wino_fused_kernel / wino_input_kernel + wino_gemm_kernel (the 16 3x3 "
-                    "layers as fp32 Winograd F(2x2,3x3)) -- the 53 conv layers of one step, priced at their direct-convolution FLOPs")
+            return ("conv_gemm_f32_dma_kernel (the 1x1 / strided / dual-source layers and the 56x56 3x3 layers) + w4_input_kernel + "
+                    "w4_gemm_kernel (the 13 3x3 layers on the 28x28 / 14x14 / 7x7 maps as fp32 Winograd F(4x4,3x3); F(2x2,3x3) / direct "
+                    "below 128 work items) -- the 53 conv layers of one step, priced at their direct-convolution FLOPs")
         return "conv_gemm_bf16_dma_kernel -- the 53 conv layers of one step, priced at their algorithmic HBM bytes"
 
     def enable_timing(self, level=1):

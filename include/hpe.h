@@ -69,7 +69,8 @@ typedef struct HpeConfig {
     int wino_fused_min_hw; /* HPE_WINO_FUSED_MINHW smallest map side on the fused path (28) */
     int mesh_a2b;          /* HPE_MESH_A2B         pixel -> vertex search of the mesh loss: 0 cell grid (default), 1 VALU full
                             *                      search, 2 matrix-core full search */
-    int wino_f4;           /* HPE_WINO_F4          3x3 layers on the 56x56 / 28x28 maps as Winograd F(4x4,3x3) */
+    int wino_f4;           /* HPE_WINO_F4          map sizes whose 3x3 layers run as Winograd F(4x4,3x3) instead of F(2x2,3x3) / direct: bit mask
+                            *                      1 = 7x7, 2 = 14x14, 4 = 28x28, 8 = 56x56 maps (7) */
     int bf16_p8;           /* HPE_BF16_P8          bf16 layer kinds on the 256 x 256 phase-interleaved GEMM kernel (N % 256 == 0, K >= 512 only):
                             *                      1 the 3x3 layers of stage 4, 2 those of stage 5, 4 1x1 / strided layers, 8 the dual-source
                             *                      launch of res5a, 16 the other dual-source launches */

@@ -181,9 +181,10 @@ def test_conv_layer_matches_oracle(engine, assets, name, B):
 
 @pytest.fixture(scope="module")
 def engines_direct_and_wino(assets):
-    """Two encoder-only contexts living side by side: every 3x3 layer direct (wino_min_c=0) / Winograd for C >= 64 at any batch
-    (the product default is C >= 128 and >= 128 work items per launch).  Plan options are HpeConfig fields, per context."""
-    made = [encoder_engine(assets, 40, wino_min_c=0), encoder_engine(assets, 40, wino_min_c=64, wino_min_items=0)]
+    """Two encoder-only contexts living side by side: every 3x3 layer direct (wino_min_c=0) / Winograd F(2x2,3x3) for C >= 64 at
+    any batch (wino_f4=0; the product default is F(4x4,3x3) on the maps up to 28x28 from 128 work items per launch on, F(2x2) for
+    C >= 128 from 128 work items on below that).  Plan options are HpeConfig fields, per context."""
+    made = [encoder_engine(assets, 40, wino_min_c=0), encoder_engine(assets, 40, wino_min_c=64, wino_min_items=0, wino_f4=0)]
     yield made
     for e in made:
         e.close()
@@ -311,17 +312,18 @@ def test_winograd_encoder_features_match_direct(engines_direct_and_wino, assets)
 
 
 def test_winograd_chunked_encoder_matches_direct(assets):
-    """B = 130 runs as two batch chunks of 65 on two streams (one chunk per >= 64 images), each with its own slice of the
-    Winograd workspace and the product's default thresholds; the features must equal the all-direct context's."""
+    """B = 130 runs as two batch chunks of 65 on two streams (one chunk per >= 44 images), each with its own slice of the
+    Winograd workspace and the product's default thresholds -- with F(2x2,3x3) only (wino_f4=0) and with the default plan
+    (F(4x4,3x3) where a chunk's launch has >= 128 work items); the features must equal the all-direct context's."""
     feats = []
     img = gpu(synthetic.make_images(130, seed=99))
-    for opts in ({"wino_min_c": 0}, {}):
+    for opts in ({"wino_min_c": 0}, {"wino_f4": 0}, {}):
         e = encoder_engine(assets, 130, **opts)
         feats.append(cpu(e.encoder(img)))
         e.close()
-    assert rel(feats[1], feats[0]) < 2e-5
+    assert rel(feats[1], feats[0]) < 2e-5 and rel(feats[2], feats[0]) < 2e-5
     ref = O.resnet50_features(cpu(img[64:66]), assets["enc"])  # images straddling the chunk boundary
-    assert rel(feats[1][64:66], ref) < TOL
+    assert rel(feats[1][64:66], ref) < TOL and rel(feats[2][64:66], ref) < TOL
 
 
 def test_winograd_streamk_matches_direct(assets):
@@ -330,7 +332,7 @@ def test_winograd_streamk_matches_direct(assets):
     parked accumulators; results must equal the direct kernel's to fp32 round-off."""
     B = 90
     outs = []
-    for opts, env in (({"wino_min_c": 0}, {}), ({}, {"HPE_WINO_STREAMK": "1"})):
+    for opts, env in (({"wino_min_c": 0}, {}), ({"wino_f4": 0}, {"HPE_WINO_STREAMK": "1"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)  # scheduling experiment knob (same arithmetic), read in hpe_finalize
         try:
