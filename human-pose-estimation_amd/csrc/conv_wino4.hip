@@ -115,6 +115,87 @@ struct W4Args {
     int ldy, relu;
 };
 
+// output transform of one workgroup's 32-tile x 64-cout block: (.) A in registers, A^T (.) across the six waves of a cout half through
+// LDS (96 KB exchange area at lds[0]), BN scale/shift, ReLU, NHWC stores.  Entered with the LDS free (all waves past their last slab).
+__device__ __forceinline__ void w4_epilogue(const W4Args& p, float* lds, f32x16 (&acc)[6], int tb, int nt, int t, int lane, int xi, int nb) {
+    const int hi = lane >> 5;
+    // ---- output transform.  (.) A in registers: P[j] = sum_nu A^T[j][nu] M[xi][nu]
+    f32x16 P[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e], a4 = acc[4][e], a5 = acc[5][e];
+        const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+        P[0][e] = a0 + s12 + s34;
+        P[1][e] = d12 + 2.f * d34;
+        P[2][e] = s12 + 4.f * s34;
+        P[3][e] = d12 + 8.f * d34 + a5;
+    }
+    // A^T (.) across the six waves of a cout half, through LDS, two output columns per pass:
+    //   exchange area [xi 6][jj 2][tile 32][cout 64] floats = 96 KB
+    const int em = t >> 4;        // gather role (threads 0 .. 511): tile within the block
+    const int eq = (t & 15) * 4;  // cout quad
+    const int n = nt * W4_N + eq;
+    const bool gather = t < 512;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    int b = 0, ty = 0, tx = 0;
+    bool live = false;
+    if (gather) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        const int tg = tb * W4_T + em;
+        live = tg < p.T;
+        if (live) {
+            b = tg / p.TT;
+            const int rem = tg - b * p.TT;
+            ty = rem / p.TW;
+            tx = rem - ty * p.TW;
+        }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        if (jp) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                lds[((xi * 2 + jj) * W4_T + m) * W4_N + 32 * nb + (lane & 31)] = P[2 * jp + jj][e];
+            }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 Q[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Q[k] = *reinterpret_cast<const f32x4*>(&lds[((k * 2 + jj) * W4_T + em) * W4_N + eq]);
+                const f32x4 s12 = Q[1] + Q[2], d12 = Q[1] - Q[2], s34 = Q[3] + Q[4], d34 = Q[3] - Q[4];
+                f32x4 o[4];
+                o[0] = Q[0] + s12 + s34;
+                o[1] = d12 + 2.f * d34;
+                o[2] = s12 + 4.f * s34;
+                o[3] = d12 + 8.f * d34 + Q[5];
+                const int ox = 4 * tx + 2 * jp + jj;
+                if (ox < p.W) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int oy = 4 * ty + i;
+                        if (oy < p.H) {
+                            f32x4 v = o[i] * sc + sh;
+                            if (p.relu) {
+                                v.x = fmaxf(v.x, 0.f);
+                                v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f);
+                                v.w = fmaxf(v.w, 0.f);
+                            }
+                            *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ABL (diagnostics builds, -DHPE_ABLATION + HPE_W4_ABL; results wrong): 1 = no V DMA, 2 = no U DMA, 4 = no MFMAs, 8 = no fragment reads
 template <int ABL>
 __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
@@ -216,81 +297,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();  // all waves out of the last slab before the epilogue reuses the LDS
 
-    // ---- output transform.  (.) A in registers: P[j] = sum_nu A^T[j][nu] M[xi][nu]
-    f32x16 P[4];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e], a4 = acc[4][e], a5 = acc[5][e];
-        const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
-        P[0][e] = a0 + s12 + s34;
-        P[1][e] = d12 + 2.f * d34;
-        P[2][e] = s12 + 4.f * s34;
-        P[3][e] = d12 + 8.f * d34 + a5;
-    }
-    // A^T (.) across the six waves of a cout half, through LDS, two output columns per pass:
-    //   exchange area [xi 6][jj 2][tile 32][cout 64] floats = 96 KB
-    const int em = t >> 4;        // gather role (threads 0 .. 511): tile within the block
-    const int eq = (t & 15) * 4;  // cout quad
-    const int n = nt * W4_N + eq;
-    const bool gather = t < 512;
-    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    int b = 0, ty = 0, tx = 0;
-    bool live = false;
-    if (gather) {
-        sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-        const int tg = tb * W4_T + em;
-        live = tg < p.T;
-        if (live) {
-            b = tg / p.TT;
-            const int rem = tg - b * p.TT;
-            ty = rem / p.TW;
-            tx = rem - ty * p.TW;
-        }
-    }
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-        if (jp) __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
-                lds[((xi * 2 + jj) * W4_T + m) * W4_N + 32 * nb + (lane & 31)] = P[2 * jp + jj][e];
-            }
-        __syncthreads();
-        if (live) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                f32x4 Q[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) Q[k] = *reinterpret_cast<const f32x4*>(&lds[((k * 2 + jj) * W4_T + em) * W4_N + eq]);
-                const f32x4 s12 = Q[1] + Q[2], d12 = Q[1] - Q[2], s34 = Q[3] + Q[4], d34 = Q[3] - Q[4];
-                f32x4 o[4];
-                o[0] = Q[0] + s12 + s34;
-                o[1] = d12 + 2.f * d34;
-                o[2] = s12 + 4.f * s34;
-                o[3] = d12 + 8.f * d34 + Q[5];
-                const int ox = 4 * tx + 2 * jp + jj;
-                if (ox < p.W) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int oy = 4 * ty + i;
-                        if (oy < p.H) {
-                            f32x4 v = o[i] * sc + sh;
-                            if (p.relu) {
-                                v.x = fmaxf(v.x, 0.f);
-                                v.y = fmaxf(v.y, 0.f);
-                                v.z = fmaxf(v.z, 0.f);
-                                v.w = fmaxf(v.w, 0.f);
-                            }
-                            *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
-                        }
-                    }
-                }
-            }
-        }
-    }
+    w4_epilogue(p, lds, acc, tb, nt, t, lane, xi, nb);
 }
 
 }  // namespace

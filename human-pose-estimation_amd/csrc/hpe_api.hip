@@ -179,6 +179,7 @@ struct hpe_ctx {
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
+    int wino4_min_items = 128;  // F(4x4) launches need at least this many workgroups (HPE_WINO4_MIN_ITEMS), else F(2x2) / direct by their rules
     int wino_f4 = 0;          // map sizes whose 3x3 layers run as Winograd F(4x4,3x3): bit 0: 7x7, 1: 14x14, 2: 28x28, 3: 56x56 (HPE_WINO_F4)
     int mesh_a2b = 0;         // pixel -> vertex search of the mesh loss: 0 cell grid, 1 VALU full search, 2 matrix-core full search
     bool loss_attr_done = false;  // per-device kernel attributes of the loss kernels set (hpe_finalize, or the first loss call of a loss-only ctx)
@@ -308,7 +309,7 @@ inline int f4_bit(int hin) { return hin <= 7 ? 1 : (hin <= 14 ? 2 : (hin <= 28 ?
 // the 3x3 layer idx runs as Winograd F(4x4,3x3) for this batch (blocked V through the workspace)
 bool use_wino4(const hpe_ctx* c, int idx, int B) {
     const ConvSpec& s = specs()[idx];
-    return !c->bf16 && c->conv[idx].wino4_u && s.kh == 3 && s.stride == 1 && hpe_wino4_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
+    return !c->bf16 && c->conv[idx].wino4_u && s.kh == 3 && s.stride == 1 && hpe_wino4_items(B, s.hin, s.hin, s.cout) >= (c->wino_min_items < c->wino4_min_items ? c->wino_min_items : c->wino4_min_items);
 }
 
 // the 3x3 layer idx runs as the fused Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
@@ -822,6 +823,7 @@ static int finalize_impl(hpe_ctx* c) {
         // F(4x4,3x3) on the 28x28 / 14x14 / 7x7 maps by default (A/B on one box: 17,720 -> 18,790 img/s; with the 7x7 and 14x14 maps only
         // 18,540; the 56x56 maps lose: their V round trip costs more than the direct kernel's extra multiplies)
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
+        c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
         c->knobs.concurrent_tiles = e ? atoi(e) : 0;
