@@ -3,6 +3,7 @@
 // row is 8 px * 4 ch = one contiguous 32-float GEMM slab), pool1_pad ZeroPadding2D(1) + MaxPooling2D(3,2),
 // and the final GlobalAveragePooling2D.  All are 16 B/lane coalesced NHWC streams.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include "hpe_internal.h"
 
@@ -75,6 +76,47 @@ __global__ void avgpool_kernel(const f32x4* __restrict__ x, float* __restrict__ 
     *reinterpret_cast<f32x4*>(y + (long)b * ldy + c * 4) = o;
 }
 
+
+// Dense layer for very small batches (M <= 4; from M = 8 on the split-K GEMM + fix-up pair is faster again): y[m][n] = act((x[m,:] . Wt[n,:]) * scale[n] + shift[n] + res[m][n]).
+// One wave per output column n (a contiguous K-float row of the packed weights, read once, 16 B per lane), all M rows of x at
+// once, wave-shuffle reduction.  ONE launch where the implicit-GEMM kernel needs a split-K launch plus a fix-up launch to occupy the
+// chip at M <= 8: the single-frame path is a chain of dependent ~8-us launches, so launches are what it pays for
+// (RegressionNetwork, reference: src/models.py:60-74; predictor loop src/predictor.py:129-133).
+template <int MM>
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const float* __restrict__ x, int lda, const float* __restrict__ wt, int K, int N,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ res, int ldres, int relu, float* __restrict__ y, int ldy, int M) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    const float* w = wt + (size_t)n * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m < M) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * lda + k);
+                acc[m] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        float v = acc[m];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && m < M) {
+            v = v * scale[n] + shift[n];
+            if (res) v += res[(size_t)m * ldres + n];
+            if (relu) v = fmaxf(v, 0.f);
+            y[(size_t)m * ldy + n] = v;
+        }
+    }
+}
+
 // theta[b][0..84] = mean[0..84]  (tf.tile(mean_var, [B,1]); reference: src/predictor.py:126)
 __global__ void tile_theta_kernel(const float* __restrict__ mean, float* __restrict__ theta, int B, int ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,6 +161,18 @@ hipError_t hpe_launch_avgpool(const float* x, float* y, int B, int HW, int C, in
     const int total = B * (C / 4);
     hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), y, B, HW,
                        C / 4, ldy);
+    return hipGetLastError();
+}
+
+hipError_t hpe_launch_dense_gemv(const float* x, int lda, int M, int K, const float* wt, int N, const float* scale, const float* shift, const float* res,
+                                 int ldres, int relu, float* y, int ldy, hipStream_t st) {
+    if (M < 1 || M > 4 || (K % 4) != 0 || (lda % 4) != 0 || N < 1 || !x || !wt || !y || !scale || !shift) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) != 0 || ((uintptr_t)wt & 15) != 0) return hipErrorInvalidValue;
+    const dim3 grid((N + 3) / 4), block(256);
+    if (M <= 2)
+        hipLaunchKernelGGL(dense_gemv_kernel<2>, grid, block, 0, st, x, lda, wt, K, N, scale, shift, res, ldres, relu, y, ldy, M);
+    else
+        hipLaunchKernelGGL(dense_gemv_kernel<4>, grid, block, 0, st, x, lda, wt, K, N, scale, shift, res, ldres, relu, y, ldy, M);
     return hipGetLastError();
 }
 

@@ -437,6 +437,8 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
 
 hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
                      const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
+    // single frames and very small batches: one launch per layer (the implicit-GEMM kernel would need split-K + a fix-up launch)
+    if (M <= 4) return hpe_launch_dense_gemv(x, lda, M, K, w, N, scale, shift, res, ldres, relu, y, ldy, st);
     GemmArgs p{};
     p.zero = shift;  // any readable 16 B: dense mode never takes the zero-page path
     // the Dense layers run after the chunk streams have joined; in the pipelined forward they overlap the NEXT batch's encoder,
@@ -1145,6 +1147,7 @@ static int finalize_impl(hpe_ctx* c) {
             if ((rc = dev_alloc(c, &c->work.A, Bpad * 288, true))) return rc;
             if ((rc = dev_alloc(c, &c->work.cams, Bpad * 4, true))) return rc;
             if ((rc = dev_alloc(c, &c->work.verts_tmp, B * HPE_NUM_VERTS * 3, false))) return rc;
+            if ((rc = dev_alloc(c, &c->work.kp_part, (size_t)SMPL_SMALL_B * ((HPE_NUM_VERTS + 63) / 64) * 72, true))) return rc;
             // reprojection-loss workspace for the geometry the path itself produces (config 5); other sizes grow it on demand
             c->loss_ws_floats = hpe_mesh_loss_ws_floats(c->cfg.max_batch, HPE_IMG_SIZE, HPE_IMG_SIZE, HPE_NUM_VERTS);
             if ((rc = dev_alloc(c, &c->loss_ws, c->loss_ws_floats, true))) return rc;

@@ -88,6 +88,9 @@ int hpe_stem_fused_pick_rows(int B);
 hipError_t hpe_launch_pad_input(const float* img, float* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);
 hipError_t hpe_launch_maxpool(const float* x, float* y, int B, int H, int C, hipStream_t st);
 hipError_t hpe_launch_avgpool(const float* x, float* y, int B, int HW, int C, int ldy, hipStream_t st);
+// Dense layer at M <= 4 rows (one launch, no split-K): wt packed [n][K], K % 4 == 0
+hipError_t hpe_launch_dense_gemv(const float* x, int lda, int M, int K, const float* wt, int N, const float* scale, const float* shift, const float* res,
+                                 int ldres, int relu, float* y, int ldy, hipStream_t st);
 hipError_t hpe_launch_tile_theta(const float* mean85, float* theta, int B, int ld, hipStream_t st);
 hipError_t hpe_launch_copy_theta(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st);
 
@@ -109,6 +112,7 @@ struct SmplDev {
 #define SMPL_V 6890
 #define SMPL_KP_PITCH 24
 #define SMPL_IMG_TILE 8
+#define SMPL_SMALL_B 8  // batches up to this size take the latency path of smpl.hip
 
 struct SmplWork {
     float* pfT;   // [207][Bpad]  pose feature, transposed
@@ -116,6 +120,7 @@ struct SmplWork {
     float* A;     // [Bpad][24][12]
     float* cams;  // [Bpad][4] (s, tx, ty, 0)
     float* verts_tmp; // [Bpad][V][3] used when the caller does not want verts but wants joints
+    float* kp_part;   // [SMPL_SMALL_B][108][72] keypoint-regressor partials of the small-batch path (nullptr: always the large-batch kernels)
     int Bpad;
 };
 

@@ -238,6 +238,146 @@ __global__ __launch_bounds__(256) void smpl_skin_kernel(SmplDev d, const float* 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Small batches (B <= 8, the single-frame latency path): one wave = 64 vertices of ONE image, grid (ceil(V/64), B) = 108 workgroups
+// per image instead of 27 per 8 images, the 207-term pose blend unrolled 23 deep (69 independent loads in flight per lane: nine
+// round trips instead of thirty-five), and the keypoint regressor's partial sums over the wave's 64 vertices taken right here from
+// the registers that hold the vertices (wave-shuffle reduction) -- smpl_kp_finish_kernel adds the 108 partials per image in a fixed
+// order.  Same arithmetic per vertex as smpl_skin_kernel (summation order of the joint regressor differs: 64-vertex groups).
+template <bool W2D>
+__global__ __launch_bounds__(64) void smpl_skin_small_kernel(SmplDev d, const float* __restrict__ pfT, const float* __restrict__ betaT,
+                                                             const float* __restrict__ A, const float* __restrict__ cams, int Bpad, int B,
+                                                             float* __restrict__ verts, float* __restrict__ verts2d, float im_w, float im_h,
+                                                             float* __restrict__ kp_part, int n_tiles) {
+    const int lane = threadIdx.x;
+    const int vraw = blockIdx.x * 64 + lane;
+    const bool vok = vraw < V;
+    const int v = vok ? vraw : V - 1;
+    const int img = blockIdx.y;
+    float vs0 = d.v_template[3 * v], vs1 = d.v_template[3 * v + 1], vs2 = d.v_template[3 * v + 2];
+    // 1. v_shaped = beta . shapedirs + v_template   (batch_smpl.py:110-112); same order of additions as the large-batch kernel:
+    //    the ten blend terms first, the template last
+    {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float* sd = d.shapedirs + (size_t)k * V3 + 3 * v;
+            const float bb = betaT[k * Bpad + img];
+            a0 += bb * sd[0];
+            a1 += bb * sd[1];
+            a2 += bb * sd[2];
+        }
+        vs0 = a0 + vs0;
+        vs1 = a1 + vs1;
+        vs2 = a2 + vs2;
+    }
+    // 3. v_posed = pose_feature . posedirs + v_shaped   (batch_smpl.py:130-132)
+    float vp0 = 0.f, vp1 = 0.f, vp2 = 0.f;
+#pragma unroll 23
+    for (int k = 0; k < 207; ++k) {
+        const float* pd = d.posedirs + (size_t)k * V3 + 3 * v;
+        const float f = pfT[k * Bpad + img];
+        vp0 += f * pd[0];
+        vp1 += f * pd[1];
+        vp2 += f * pd[2];
+    }
+    // 5. skinning: T = W . A ; verts = (T . [v_posed; 1])[:3]   (batch_smpl.py:139-149)
+    float w[24];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(d.weights + (size_t)v * 24);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const f32x4 t = wp[q];
+            w[4 * q] = t.x;
+            w[4 * q + 1] = t.y;
+            w[4 * q + 2] = t.z;
+            w[4 * q + 3] = t.w;
+        }
+    }
+    const float* Ai = A + (size_t)img * 288;
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 24; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] += w[jj] * Ai[jj * 12 + e];
+    }
+    const float px = vp0 + vs0, py = vp1 + vs1, pz = vp2 + vs2;
+    const float ox = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    const float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+    const float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    if (vok && verts) {
+        float* o = verts + ((size_t)img * V + v) * 3;
+        o[0] = ox;
+        o[1] = oy;
+        o[2] = oz;
+    }
+    if (W2D && vok) {
+        const float* cm = cams + img * 4;
+        float* o2 = verts2d + ((size_t)img * V + v) * 2;
+        o2[0] = ((cm[0] * (ox + cm[1])) + 1.0f) * 0.5f * im_w;
+        o2[1] = ((cm[0] * (oy + cm[2])) + 1.0f) * 0.5f * im_h;
+    }
+    if (kp_part) {
+        // keypoint regressor (batch_smpl.py:152-155), partial over this wave's 64 vertices
+        const float x0 = vok ? ox : 0.f, x1 = vok ? oy : 0.f, x2 = vok ? oz : 0.f;
+        const f32x4* rp = reinterpret_cast<const f32x4*>(d.kp_reg + (size_t)v * 24);
+        float* out = kp_part + ((size_t)img * n_tiles + blockIdx.x) * 72;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const f32x4 r = rp[q];
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s0 = x0 * rr[u], s1 = x1 * rr[u], s2 = x2 * rr[u];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    s0 += __shfl_xor(s0, off, 64);
+                    s1 += __shfl_xor(s1, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (lane == 0) {
+                    out[(4 * q + u) * 3 + 0] = s0;
+                    out[(4 * q + u) * 3 + 1] = s1;
+                    out[(4 * q + u) * 3 + 2] = s2;
+                }
+            }
+        }
+    }
+}
+
+// joints[n][k][c] = sum over the n_tiles partials (fixed order: four interleaved groups, then the groups); optional fused
+// batch_orth_proj_idrot.  288 threads = 72 sums x 4 groups, so that the loads of a sum are 27 independent ones, not 108 in a chain.
+__global__ __launch_bounds__(288) void smpl_kp_finish_kernel(const float* __restrict__ kp_part, int n_tiles, int K, float* __restrict__ out,
+                                                             const float* __restrict__ cams, float* __restrict__ kp2d) {
+    __shared__ float grp[4][72];
+    __shared__ float fin[72];
+    const int n = blockIdx.x;
+    const int t = threadIdx.x;
+    const int e = t % 72, g = t / 72;
+    {
+        const float* p = kp_part + (size_t)n * n_tiles * 72 + e;
+        float s = 0.f;
+#pragma unroll 9
+        for (int i = g; i < n_tiles; i += 4) s += p[(size_t)i * 72];
+        grp[g][e] = s;
+    }
+    __syncthreads();
+    if (t < 72) {
+        const float s = (grp[0][t] + grp[1][t]) + (grp[2][t] + grp[3][t]);
+        fin[t] = s;
+        if (t < K * 3 && out) out[(size_t)n * K * 3 + t] = s;
+    }
+    __syncthreads();
+    if (kp2d && t < K * 2) {
+        const int k = t >> 1, c = t & 1;
+        const float* cm = cams + n * 4;
+        kp2d[(size_t)n * K * 2 + t] = cm[0] * (fin[k * 3 + c] + cm[1 + c]);  // projection.py:27-33
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[n][k][c] = sum_v X[n][v][c] * reg[v][k], k < K <= 24 (reg rows are 24 floats, zero padded).
 // one 256-thread workgroup per n.  Optional fused batch_orth_proj_idrot: kp2d[n][k][0:2] = s*(out[..,:2] + t).
@@ -339,6 +479,22 @@ hipError_t hpe_launch_smpl(const SmplDev& d, const SmplWork& w, const float* the
     if (e != hipSuccess) return e;
     const bool need_verts = o->verts || o->joints || o->kp2d || o->verts2d;
     if (!need_verts) return hipSuccess;
+    if (B <= SMPL_SMALL_B && w.kp_part) {
+        // latency path: 108 one-wave workgroups per image, keypoint partials from the skin kernel's registers, one finish launch
+        const int n_tiles = (V + 63) / 64;
+        const bool want_kp = o->joints || o->kp2d;
+        dim3 g(n_tiles, B);
+        if (o->verts2d)
+            hipLaunchKernelGGL(smpl_skin_small_kernel<true>, g, dim3(64), 0, st, d, w.pfT, w.betaT, w.A, w.cams, w.Bpad, B, o->verts, o->verts2d,
+                               (float)HPE_IMG_SIZE, (float)HPE_IMG_SIZE, want_kp ? w.kp_part : nullptr, n_tiles);
+        else
+            hipLaunchKernelGGL(smpl_skin_small_kernel<false>, g, dim3(64), 0, st, d, w.pfT, w.betaT, w.A, w.cams, w.Bpad, B, o->verts,
+                               (float*)nullptr, 0.f, 0.f, want_kp ? w.kp_part : nullptr, n_tiles);
+        e = hipGetLastError();
+        if (e != hipSuccess || !want_kp) return e;
+        hipLaunchKernelGGL(smpl_kp_finish_kernel, dim3(B), dim3(288), 0, st, w.kp_part, n_tiles, d.num_kp, o->joints, w.cams, o->kp2d);
+        return hipGetLastError();
+    }
     float* verts = o->verts ? o->verts : w.verts_tmp;
     dim3 grid((V + 255) / 256, Bpad / IT);
     if (o->verts2d)

@@ -1,7 +1,14 @@
 """Generates tests/golden/losses_b2.npz with the CPU oracle: the config-5 losses (src/ops.py:35-137, src/trainer.py:274-296) of
 the three IEF stages on the golden path's own outputs (images of tests/golden/make_golden.py, seeded silhouettes / keypoints).
-Produced by the oracle restatement in the build container ("parity unpinned" w.r.t. the reference's own outputs); pins the loss
-oracle against drift and the HIP loss kernels on inputs a forward pass produces.  Run:  python tests/golden/make_loss_golden.py
+Produced by the oracle restatement in the build container -- ORACLE-GENERATED, i.e. "parity unpinned" w.r.t. the reference's own
+outputs (the reference holds no fixture for src/ops.py and cannot run here); it pins the loss oracle against drift and the HIP loss
+kernels on inputs a forward pass produces.  The quirks of the reference it encodes, each restated from the cited lines only:
+  * silhouette points are (x = column, y = row) in tf.where order (row-major)            src/trainer.py:291, src/ops.py:123-125
+  * L2 distance B -> A, L1 distance A -> B                                                src/ops.py:91-96
+  * the denominator is silhouette_gt.shape[1] + silhouette_pred.shape[1] = 3 + 6890      src/ops.py:129-130
+  * kp loss = sum(vis * |d|) / (2 * #visible), 0 when nothing is visible                  src/ops.py:35-47 (SUM_BY_NONZERO_WEIGHTS)
+The nearest-neighbour part alone has an independent pin (scipy cKDTree, tests/test_oracle_kat.py).
+Run:  python tests/golden/make_loss_golden.py
 """
 import os
 import sys

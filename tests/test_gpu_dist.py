@@ -52,5 +52,11 @@ def test_bench_launches_its_own_ranks(extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
     assert "RCCL all-gather" in d["config"]["workload"]
+    # the N > 1 line verifies itself: every rank checks its slice of the gathered theta against its own theta and two images of
+    # its last batch against the oracle; the flags are all-reduced (MIN) into the one JSON line
+    dc = d["dist_check"]
+    assert dc["ranks"] == 1 and dc["gather_slice_equals_local_theta_on_every_rank"] is True and dc["parity_pass_on_every_rank"] is True
+    assert 0 < dc["worst_gated_over_ranks"] < 1e-4 and dc["images_checked_per_rank"] == 2
     if extra:
         assert len(d["losses_last_step"]["kpr"]) == 3 and d["loss_roofline"]["achieved"] > 0
+        assert d["loss_roofline"]["frac"] <= 1.0 and d["loss_roofline"]["mfma_grid_search"] + d["loss_roofline"]["mfma_full_search"] > 0

@@ -44,7 +44,7 @@ def main():
             with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (name, tag)), "w") as f:
                 f.write(csv)
     for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "layers_*.txt")) + glob.glob(os.path.join(src, "power_trace_*.csv")) + \
-            glob.glob(os.path.join(src, "latency_small_batch.txt")) + glob.glob(os.path.join(src, "mesh_loss_search.txt")):
+            glob.glob(os.path.join(src, "latency_*.txt")) + glob.glob(os.path.join(src, "mesh_loss_search.txt")):
         shutil.copy(f, os.path.join(dst, os.path.basename(f)))
     kt3 = os.path.join(src, "prof_fp32", "kt3", "kt3_results.db")
     if os.path.isfile(kt3):

@@ -85,7 +85,7 @@ def main():
         tot_t += ms
         tot_b += fb + wb
     print("\ntotal %.2f ms, %.2f GB" % (tot_t, tot_b / 1e9))
-    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream")]
+    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("w4_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream")]
     cf = sum(fetch.get(k, 0.0) for k in conv)
     cw = sum(write.get(k, 0.0) for k in conv)
     print("\nJSON " + json.dumps({"fetch_bytes_corrected": cf, "write_bytes": cw, "total_bytes": cf + cw, "kernels": sorted(conv)}))
