@@ -484,6 +484,9 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
                     const float m4 = fminf(fminf(d[g][12], d[g][13]), d[g][14]);
                     const float m5 = fminf(fminf(m0, m1), d[g][15]);
                     const float m = fminf(fminf(m2, m3), fminf(m4, m5));
+                    // most chunks of the outer rings improve no pixel of the tile: one compare + ballot skips the bookkeeping
+                    // (pixels outside the silhouette are never read back: they do not keep a chunk alive)
+                    if (!__any(active[g] && m <= best[g])) continue;
                     const bool lt = m < best[g];
                     const bool eq = m == best[g];
                     best[g] = fminf(m, best[g]);
