@@ -300,6 +300,268 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
     w4_epilogue(p, lds, acc, tb, nt, t, lane, xi, nb);
 }
 
+// ------------------------------------------------------------------------------------------------ fused input transform (56x56 / 28x28 maps)
+// The same GEMM without V in memory: the producing 1x1 convolution writes its output channel-slab major, Xs[slab of 8 ch][pixel][8]
+// (GemmArgs::y_slab8, as for wino_fused_kernel), and a workgroup owns R consecutive tile rows of the batch -- 2 x 14 tiles on the 56x56
+// maps, 4 x 7 on the 28x28 maps: 28 of its 32 tile slots -- for one 64-cout block.  Per 4-channel slab (half of an 8-channel record: 16 B
+// per pixel) the 6 input rows of every tile row arrive by LDS-DMA as raw[tile row][6][W + 2][4 ch] (zero page for the halo; <= 720 chunks =
+// ONE wave-instruction per wave), and 168 (tile, xi) pairs, 14 lanes of every wave, turn them into the V slab image the MFMA loop reads:
+// row xi of B^T d for the six columns, then (.) B.  The MFMA work of slab s overlaps the transform of slab s+1 and the DMAs of
+// U(s+1) and raw(s+2); one barrier per slab.  LDS: V 2 x 18 KB + U 2 x 36 KB + raw 2 x 12 KB = 132 KB.
+struct W4FusedArgs {
+    const float* Xs;     // [C/8][M][8]
+    const float* U;
+    const float* scale;
+    const float* shift;
+    const float* zero;   // >= 16 B of zeros
+    float* y;
+    int H, W, TW, TH;    // map, tiles per row / per column (W / 4, H / 4)
+    int R, NG;           // tile rows per workgroup, tile rows in the batch (B * TH)
+    int n_blk, n_nt, S;  // workgroups along the tile rows, cout blocks, 4-channel slabs (C / 4)
+    int NC;              // raw chunks per slab (R * 6 * (W + 2))
+    long M;              // pixels in the batch (B * H * W)
+    int ldy, relu;
+};
+
+constexpr int W4F_RAW = 768 * 4;  // floats per raw buffer (768 chunks >= 2*6*58 = 696 and 4*6*30 = 720)
+constexpr int W4F_BUF = W4_VS + W4_US + W4F_RAW;  // 16896 floats
+constexpr int W4F_LDS_BYTES = 2 * W4F_BUF * (int)sizeof(float);  // 132 KB
+
+__constant__ float w4_bt[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+
+// MAPW: the map side (56 or 28), a template parameter so that the 36 raw reads of the transform are ONE address register plus immediate
+// offsets (with a run-time row pitch hipcc keeps 36 address VGPRs alive and spills the accumulators)
+template <int MAPW>
+__global__ __launch_bounds__(W4_THREADS, 1) void w4_fused_kernel(W4FusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf 2][V | U | raw]
+
+    const int total = p.n_blk * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int blk = lid / p.n_nt;
+    const int nt = lid - blk * p.n_nt;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int xi = wave >> 1;
+    const int nb = wave & 1;
+    const int hi = lane >> 5;
+    const int S = p.S;
+    constexpr int Wp = MAPW + 2;
+    constexpr int TW = MAPW / 4;
+
+    // ---- raw DMA source of this lane: chunk c = wave * 64 + lane -> (tile row, input row a, padded column xp)
+    long rsrc = -1;  // float offset inside an 8-channel slab of Xs (without the half), or -1 for the zero page
+    {
+        const int c = wave * 64 + lane;
+        if (c < p.NC) {
+            const int xp = c % Wp;
+            const int ra = c / Wp;
+            const int a = ra % 6;
+            const int trl = ra / 6;
+            const int g = blk * p.R + trl;
+            if (g < p.NG) {
+                const int b = g / p.TH;
+                const int ty = g - b * p.TH;
+                const int iy = 4 * ty - 1 + a, ix = xp - 1;
+                if (iy >= 0 && iy < MAPW && ix >= 0 && ix < MAPW) rsrc = ((long)(b * MAPW + iy) * MAPW + ix) * 8;
+            }
+        }
+    }
+    const bool raw_wave = wave * 64 < p.NC;
+    const float* usrc = p.U + (size_t)nt * S * W4_US + lane * 4;
+
+    auto issue_raw = [&](int s, int buf) {
+        if (!raw_wave) return;
+        const float* src = rsrc >= 0 ? p.Xs + (size_t)(s >> 1) * p.M * 8 + rsrc + (s & 1) * 4 : p.zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + buf * W4F_BUF + W4_VS + W4_US + wave * 256), 16, 0, 0);
+    };
+    auto issue_u = [&](int s, int buf) {
+        const float* su = usrc + (size_t)s * W4_US;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = wave + 12 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(su + k * 256),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * W4F_BUF + W4_VS + k * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- transform role: wave (xi, nb) computes row xi of B^T d -- the same row it multiplies, so the six coefficients are
+    //      wave-uniform (SGPRs) -- for tiles 14 nb .. 14 nb + 13, two channels per lane: lanes 0 .. 27 = (tile, channel pair)
+    const int n_tiles = p.R * TW;
+    const int t_tile = 14 * nb + (lane >> 1);
+    const int chp = lane & 1;
+    const bool t_live = lane < 28 && t_tile < n_tiles;
+    const int t_trl = t_live ? t_tile / TW : 0;
+    const int t_tx = t_live ? t_tile - t_trl * TW : 0;
+    float cf[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) cf[a] = w4_bt[xi][a];
+    const int raw0 = ((t_trl * 6) * Wp + 4 * t_tx) * 4 + 2 * chp;  // float offset of input row 0, tile column 0, this lane's channel pair
+    auto transform = [&](int rbuf, int vbuf) {
+        if (!t_live) return;
+        const float* rw = lds + rbuf * W4F_BUF + W4_VS + W4_US + raw0;
+        f32x2 r[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            f32x2 d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) d[a] = *reinterpret_cast<const f32x2*>(rw + (a * Wp + e) * 4);
+            r[e] = cf[0] * d[0] + cf[1] * d[1] + cf[2] * d[2] + cf[3] * d[3] + cf[4] * d[4] + cf[5] * d[5];
+        }
+        f32x2 o[6];
+        W4_BT(o[0], o[1], o[2], o[3], o[4], o[5], r[0], r[1], r[2], r[3], r[4], r[5]);
+        float* v = lds + vbuf * W4F_BUF + (xi * 6) * (W4_T * 4) + t_tile * 4 + 2 * chp;
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x2*>(v + nu * (W4_T * 4)) = o[nu];
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+    const int fv = (xi * 6) * (W4_T * 4) + (lane & 31) * 4 + 2 * hi;
+    const int fu = W4_VS + (xi * 6) * (W4_N * 4) + (32 * nb + (lane & 31)) * 4 + 2 * hi;
+
+    issue_raw(0, 0);
+    issue_u(0, 0);
+    if (S > 1) issue_raw(1, 1);
+    // tile slots that belong to no tile are never written by the transform: clear them once in both V buffers
+    if (n_tiles < W4_T) {
+        const int dead = W4_T - n_tiles;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = t; i < 2 * 36 * dead; i += W4_THREADS) {
+            const int row = n_tiles + i % dead;
+            const int comp = (i / dead) % 36;
+            const int buf = i / (dead * 36);
+            *reinterpret_cast<f32x4*>(lds + buf * W4F_BUF + (comp * W4_T + row) * 4) = z;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    transform(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < S; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < S) issue_u(s + 1, nxt);
+        if (s + 2 < S) issue_raw(s + 2, cur);
+        const int cb = cur * W4F_BUF;
+        // first-half fragments and MFMAs, then the transform of the next slab while they run, then the second half: the transform's
+        // ~50 VGPRs and a half's 12 fragment VGPRs are never live together with the other half's (96 accumulators + 168-VGPR budget)
+        {
+            f32x2 fa[3], fb[3];
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu) {
+                fa[nu] = *reinterpret_cast<const f32x2*>(&lds[cb + fv + nu * (W4_T * 4)]);
+                fb[nu] = *reinterpret_cast<const f32x2*>(&lds[cb + fu + nu * (W4_N * 4)]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nu = 0; nu < 3; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S) transform(nxt, nxt);  // raw(s+1) landed behind the barrier that ended slab s-1
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            f32x2 fa[3], fb[3];
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu) {
+                fa[nu] = *reinterpret_cast<const f32x2*>(&lds[cb + fv + (nu + 3) * (W4_T * 4)]);
+                fb[nu] = *reinterpret_cast<const f32x2*>(&lds[cb + fu + (nu + 3) * (W4_N * 4)]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nu = 0; nu < 3; ++nu) acc[nu + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu + 3], 0, 0, 0);
+        }
+        // U(s+1) and raw(s+2) have landed, V(s+1) is written, every wave is done with V(s) / U(s)
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- output transform (w4_epilogue with this kernel's tile -> pixel mapping)
+    f32x16 P[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e], a4 = acc[4][e], a5 = acc[5][e];
+        const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+        P[0][e] = a0 + s12 + s34;
+        P[1][e] = d12 + 2.f * d34;
+        P[2][e] = s12 + 4.f * s34;
+        P[3][e] = d12 + 8.f * d34 + a5;
+    }
+    const int em = t >> 4;
+    const int eq = (t & 15) * 4;
+    const int n = nt * W4_N + eq;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    int b = 0, ty = 0, tx = 0;
+    bool live = false;
+    if (t < 512) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        const int trl = em / TW;
+        tx = em - trl * TW;
+        const int g = blk * p.R + trl;
+        live = em < n_tiles && g < p.NG;
+        if (live) {
+            b = g / p.TH;
+            ty = g - b * p.TH;
+        }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        if (jp) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                lds[((xi * 2 + jj) * W4_T + m) * W4_N + 32 * nb + (lane & 31)] = P[2 * jp + jj][e];
+            }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 Q[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Q[k] = *reinterpret_cast<const f32x4*>(&lds[((k * 2 + jj) * W4_T + em) * W4_N + eq]);
+                const f32x4 s12 = Q[1] + Q[2], d12 = Q[1] - Q[2], s34 = Q[3] + Q[4], d34 = Q[3] - Q[4];
+                f32x4 o[4];
+                o[0] = Q[0] + s12 + s34;
+                o[1] = d12 + 2.f * d34;
+                o[2] = s12 + 4.f * s34;
+                o[3] = d12 + 8.f * d34 + Q[5];
+                const int ox = 4 * tx + 2 * jp + jj;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int oy = 4 * ty + i;
+                    f32x4 v = o[i] * sc + sh;
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // hipFuncSetAttribute applies to the CURRENT device: hpe_finalize calls this once per ctx under its device guard
@@ -309,7 +571,62 @@ hipError_t hpe_wino4_init_device() {
                           (const void*)w4_gemm_kernel<8>, (const void*)w4_gemm_kernel<12>})
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
 #endif
+    hipError_t ef = hipFuncSetAttribute(reinterpret_cast<const void*>(w4_fused_kernel<56>), hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
+    if (ef != hipSuccess) return ef;
+    ef = hipFuncSetAttribute(reinterpret_cast<const void*>(w4_fused_kernel<28>), hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
+    if (ef != hipSuccess) return ef;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(w4_gemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+}
+
+// fused-transform variant: maps with H, W multiples of 4 and W / 4 <= 32 tiles per row; xs channel-slab major [C/8][B*H*W][8]
+static bool w4_fused_geometry(int B, int H, int W, int* R_out, int* NC_out) {
+    if (H != W || (W != 56 && W != 28)) return false;  // the two instantiations of w4_fused_kernel
+    const int TW = W / 4;
+    if (TW > W4_T) return false;
+    int R = W4_T / TW;
+    while (R > 1 && R * 6 * (W + 2) > 768) --R;
+    if (R * 6 * (W + 2) > 768) return false;
+    if (R > (H / 4) * B) R = (H / 4) * B;
+    *R_out = R;
+    *NC_out = R * 6 * (W + 2);
+    return R >= 1;
+}
+
+int hpe_wino4_fused_items(int B, int H, int W, int N) {
+    int R, NC;
+    if (!w4_fused_geometry(B, H, W, &R, &NC)) return 0;
+    return ((B * (H / 4) + R - 1) / R) * (N / W4_N);
+}
+
+hipError_t hpe_launch_wino4_fused_conv3(const float* xs, const float* U, const float* scale, const float* shift, const float* zero16, float* y,
+                                        int ldy, int B, int H, int W, int C, int N, int relu, hipStream_t st) {
+    int R, NC;
+    if (C % 8 != 0 || N % 64 != 0 || ldy % 4 != 0 || B < 1 || !xs || !U || !y || !zero16 || !w4_fused_geometry(B, H, W, &R, &NC)) return hipErrorInvalidValue;
+    W4FusedArgs p{};
+    p.Xs = xs;
+    p.U = U;
+    p.scale = scale;
+    p.shift = shift;
+    p.zero = zero16;
+    p.y = y;
+    p.H = H;
+    p.W = W;
+    p.TW = W / 4;
+    p.TH = H / 4;
+    p.R = R;
+    p.NG = B * p.TH;
+    p.n_blk = (p.NG + R - 1) / R;
+    p.n_nt = N / W4_N;
+    p.S = C / 4;
+    p.NC = NC;
+    p.M = (long)B * H * W;
+    p.ldy = ldy;
+    p.relu = relu;
+    if (W == 56)
+        hipLaunchKernelGGL(w4_fused_kernel<56>, dim3(p.n_blk * p.n_nt), dim3(W4_THREADS), W4F_LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(w4_fused_kernel<28>, dim3(p.n_blk * p.n_nt), dim3(W4_THREADS), W4F_LDS_BYTES, st, p);
+    return hipGetLastError();
 }
 
 size_t hpe_wino4_v_floats(int B, int H, int W, int C) {

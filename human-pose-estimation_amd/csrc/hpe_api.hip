@@ -180,6 +180,7 @@ struct hpe_ctx {
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
     int wino4_min_items = 128;  // F(4x4) launches need at least this many workgroups (HPE_WINO4_MIN_ITEMS), else F(2x2) / direct by their rules
+    int wino4_fused = 0;      // map sizes (bits as wino_f4: 4 = 28x28, 8 = 56x56) whose F(4x4) layers take the fused-transform kernel (HPE_WINO4_FUSED)
     int wino_f4 = 0;          // map sizes whose 3x3 layers run as Winograd F(4x4,3x3): bit 0: 7x7, 1: 14x14, 2: 28x28, 3: 56x56 (HPE_WINO_F4)
     int mesh_a2b = 0;         // pixel -> vertex search of the mesh loss: 0 cell grid, 1 VALU full search, 2 matrix-core full search
     bool loss_attr_done = false;  // per-device kernel attributes of the loss kernels set (hpe_finalize, or the first loss call of a loss-only ctx)
@@ -309,13 +310,21 @@ inline int f4_bit(int hin) { return hin <= 7 ? 1 : (hin <= 14 ? 2 : (hin <= 28 ?
 // the 3x3 layer idx runs as Winograd F(4x4,3x3) for this batch (blocked V through the workspace)
 bool use_wino4(const hpe_ctx* c, int idx, int B) {
     const ConvSpec& s = specs()[idx];
-    return !c->bf16 && c->conv[idx].wino4_u && s.kh == 3 && s.stride == 1 && hpe_wino4_items(B, s.hin, s.hin, s.cout) >= (c->wino_min_items < c->wino4_min_items ? c->wino_min_items : c->wino4_min_items);
+    return !c->bf16 && c->conv[idx].wino4_u && s.kh == 3 && s.stride == 1 && (c->wino_f4 & f4_bit(s.hin)) &&
+           hpe_wino4_items(B, s.hin, s.hin, s.cout) >= (c->wino_min_items < c->wino4_min_items ? c->wino_min_items : c->wino4_min_items);
 }
 
-// the 3x3 layer idx runs as the fused Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
+// ... with the input transform inside the GEMM kernel (its 1x1 producer then writes channel-slab major); takes precedence over use_wino4
+bool use_wino4_fused(const hpe_ctx* c, int idx, int B) {
+    const ConvSpec& s = specs()[idx];
+    return !c->bf16 && c->conv[idx].wino4_u && s.kh == 3 && s.stride == 1 && (c->wino4_fused & f4_bit(s.hin)) &&
+           hpe_wino4_fused_items(B, s.hin, s.hin, s.cout) >= (c->wino_min_items < c->wino4_min_items ? c->wino_min_items : c->wino4_min_items);
+}
+
+// the 3x3 layer idx runs as the fused F(2x2) Winograd kernel for this batch (its 1x1 producer then writes channel-slab major)
 bool use_wino_fused(const hpe_ctx* c, int idx, int B) {
     const ConvSpec& s = specs()[idx];
-    if (use_wino4(c, idx, B)) return false;
+    if (use_wino4_fused(c, idx, B) || use_wino4(c, idx, B)) return false;
     return c->wino_fused && !c->bf16 && c->conv[idx].wino_u && s.kh == 3 && s.stride == 1 && s.hin >= c->wino_fused_min_hw &&
            hpe_wino_fused_items(B, s.hin, s.hin, s.cout) >= c->wino_min_items;
 }
@@ -326,6 +335,8 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
                     float* wino_v = nullptr, int slot = 0, int flags = 0) {
     const ConvSpec& s = specs()[idx];
     const ConvLayer& L = c->conv[idx];
+    if ((flags & CONV_IN_SLAB8) && use_wino4_fused(c, idx, B))
+        return hpe_launch_wino4_fused_conv3(x, L.wino4_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
     if (flags & CONV_IN_SLAB8)
         return hpe_launch_wino_fused_conv3(x, L.wino_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
     if (wino_v && !res && use_wino4(c, idx, B))
@@ -515,7 +526,7 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
         for (int b = 0; b < nblk[stg]; ++b) {
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
-            const bool fz = use_wino_fused(c, i2b, B);  // then T1 is channel-slab major and never leaves this pair of launches
+            const bool fz = use_wino_fused(c, i2b, B) || use_wino4_fused(c, i2b, B);  // then T1 is channel-slab major and never leaves this pair of launches
             HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, cf | (fz ? CONV_OUT_SLAB8 : 0)));
             HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot, cf | (fz ? CONV_IN_SLAB8 : 0)));
             const float* res = cur;
@@ -644,7 +655,7 @@ void hpe_config_init(HpeConfig* cfg) {
     cfg->bn_eps = 1e-3f;
     cfg->encoder_dtype = 0;
     cfg->n_streams = cfg->dual_gemm = cfg->stem_fused = cfg->wino_min_c = cfg->wino_min_items = cfg->wino_fused = -1;
-    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->bf16_p8 = -1;
+    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = -1;
 }
 
 int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
@@ -826,6 +837,7 @@ static int finalize_impl(hpe_ctx* c) {
         // 18,540; the 56x56 maps lose: their V round trip costs more than the direct kernel's extra multiplies)
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
+        c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
         c->knobs.concurrent_tiles = e ? atoi(e) : 0;
@@ -957,7 +969,7 @@ static int finalize_impl(hpe_ctx* c) {
                 }
             if ((rc = upload(c, &L.wino_u, U))) return rc;
         }
-        if (c->wino_f4 && s.kh == 3 && s.stride == 1 && s.cin % 32 == 0 && s.cout % 64 == 0 && (c->wino_f4 & f4_bit(s.hin))) {
+        if (s.kh == 3 && s.stride == 1 && s.cin % 32 == 0 && s.cout % 64 == 0 && ((c->wino_f4 | c->wino4_fused) & f4_bit(s.hin))) {
             // F(4x4,3x3): U = G g G^T with G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], in double;
             // layout [cout/64][cin/4][36][64][4]
             static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -1561,7 +1573,7 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
         HIP_TRY(hpe_launch_pad_input(x, c->padded, B, HPE_IMG_SIZE, HPE_IMG_SIZE, STEM_HP, STEM_WP, st));
         in = c->padded;
     }
-    if (!residual && use_wino_fused(c, idx, B)) {
+    if (!residual && (use_wino_fused(c, idx, B) || use_wino4_fused(c, idx, B))) {
         // the fused Winograd kernel reads channel-slab major input; in the network its 1x1 producer writes that directly
         const ConvSpec& s = specs()[idx];
         HIP_TRY(hpe_launch_nhwc_to_slab8(in, c->T1, (long)B * s.hin * s.hin, s.cin, st));

@@ -66,6 +66,11 @@ hipError_t hpe_wino4_init_device();
 hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
                                   int H, int W, int C, int N, int relu, float* V, hipStream_t st);
 
+// fused-transform F(4x4,3x3) (56x56 / 28x28 maps): xs is channel-slab major [C/8][B*H*W][8] (GemmArgs::y_slab8 of the producer)
+hipError_t hpe_launch_wino4_fused_conv3(const float* xs, const float* U, const float* scale, const float* shift, const float* zero16, float* y,
+                                        int ldy, int B, int H, int W, int C, int N, int relu, hipStream_t st);
+int hpe_wino4_fused_items(int B, int H, int W, int N);  // workgroups of that launch, 0 if the geometry is not supported
+
 // conv_gemm_bf16.hip (x / w / res / y of GemmArgs point to bf16 data; offsets are in bf16 elements; K % 64 == 0)
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ring_depth, hipStream_t st);  // ring_depth 2..4 LDS slab buffers
 // conv_gemm_bf16_p8.hip: 256 x 256 x 64 tile, 8 waves, phase-interleaved main loop, split-K through p.partial (DENSE / STRIDED / CONV3 / DUAL)

@@ -71,6 +71,8 @@ typedef struct HpeConfig {
                             *                      search, 2 matrix-core full search */
     int wino_f4;           /* HPE_WINO_F4          map sizes whose 3x3 layers run as Winograd F(4x4,3x3) instead of F(2x2,3x3) / direct: bit mask
                             *                      1 = 7x7, 2 = 14x14, 4 = 28x28, 8 = 56x56 maps (7) */
+    int wino4_fused;       /* HPE_WINO4_FUSED      map sizes (4 = 28x28, 8 = 56x56) whose F(4x4) layers transform their input inside the GEMM kernel
+                            *                      (no V round trip; takes precedence over wino_f4 for those maps) */
     int bf16_p8;           /* HPE_BF16_P8          bf16 layer kinds on the 256 x 256 phase-interleaved GEMM kernel (N % 256 == 0, K >= 512 only):
                             *                      1 the 3x3 layers of stage 4, 2 those of stage 5, 4 1x1 / strided layers, 8 the dual-source
                             *                      launch of res5a, 16 the other dual-source launches */

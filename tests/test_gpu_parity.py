@@ -263,6 +263,34 @@ def test_winograd4_conv_matches_oracle(engine_wino4, engines_direct_and_wino, as
     assert rel(cpu(engine_wino4.debug_conv(idx, gpu(x), relu=False)), lin) < 5e-5  # negative side preserved
 
 
+@pytest.mark.parametrize("name", ["res2b_branch2b", "res2c_branch2b", "res3a_branch2b", "res3d_branch2b"])
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_winograd4_fused_conv_matches_oracle(assets, name, B):
+    """F(4x4,3x3) with the input transform inside the GEMM kernel (w4_fused_kernel; the producer's channel-slab-major output is made
+    by the debug entry): 2 x 14 tiles per workgroup on the 56x56 maps, 4 x 7 on the 28x28 maps (tile rows of a workgroup may
+    belong to two images; B = 37 leaves a partly filled last workgroup).  Same tolerances as the blocked-V kernel."""
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    if B == 37 and s.hin > 28:
+        pytest.skip("oracle conv at this size is slow; covered by B = 3")
+    e = encoder_engine(assets, 40, wino4_fused=12, wino_min_items=0)
+    g = np.random.Generator(np.random.Philox(3500 + idx + B))
+    x = g.normal(0, 1, (B, s.hin, s.hin, s.cin)).astype(np.float32)
+    x[g.random(x.shape) < 0.3] = 0.0
+    x[0, 0, 0, :] = 50.0
+    x[B - 1, s.hin - 1, s.hin - 1, :] = -30.0  # the opposite corner of the last image
+    yw = cpu(e.debug_conv(idx, gpu(x), relu=True))
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    lin = O.conv2d_nhwc(x, p[s.name + "/kernel"], p[s.name + "/bias"], 1, 1, dtype=np.float64) * sc + sh
+    ref = np.maximum(lin, 0)
+    l2 = float(np.linalg.norm(yw - ref) / np.linalg.norm(ref))
+    print("%s B=%d  fused F(4x4): max rel %.3g, rel-L2 %.3g" % (name, B, rel(yw, ref), l2))
+    assert rel(yw, ref) < 5e-5 and l2 < 2e-5, (rel(yw, ref), l2)
+    assert rel(cpu(e.debug_conv(idx, gpu(x), relu=False)), lin) < 5e-5
+    e.close()
+
+
 def test_winograd4_encoder_features(engine_wino4, engines_direct_and_wino, assets):
     """Whole encoder with all sixteen 3x3 layers as F(4x4,3x3): the per-layer error does not accumulate -- features stay within
     fp32 round-off of the all-direct context and of the oracle."""
@@ -275,15 +303,15 @@ def test_winograd4_encoder_features(engine_wino4, engines_direct_and_wino, asset
     assert rel(fw, ref) < 1e-5
 
 
-@pytest.mark.parametrize("B,streams", [(100, 1), (256, 2)])
-def test_winograd4_full_size_equals_direct(assets, B, streams):
+@pytest.mark.parametrize("B,streams,fused", [(100, 1, 0), (256, 2, 0), (256, 2, 12)])
+def test_winograd4_full_size_equals_direct(assets, B, streams, fused):
     """Metric-size launches (200 ... 512 workgroups of the F(4x4) GEMM in flight, one or two chunk streams): features and two layers
     equal the all-direct context's.  This is the test that catches a staging race -- the first version of w4_gemm_kernel lost its
     vmcnt wait in front of the mid-slab barrier and produced whole wrong tile blocks only from ~200 workgroups on."""
     img = gpu(synthetic.make_images(B, seed=9))
     base = encoder_engine(assets, B, wino_min_c=0, n_streams=1)
     f0 = cpu(base.encoder(img))
-    e = encoder_engine(assets, B, wino_f4=3, n_streams=streams)
+    e = encoder_engine(assets, B, wino_f4=3 if not fused else 7, wino4_fused=fused, n_streams=streams)
     for _ in range(3):
         f = cpu(e.encoder(img))
         bad = np.where(np.abs(f - f0).max(1) / np.abs(f0).max() > 2e-5)[0]
