@@ -300,6 +300,164 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_gemm_kernel(W4Args p) {
     w4_epilogue(p, lds, acc, tb, nt, t, lane, xi, nb);
 }
 
+// ---- 32-cout variant for launches that would leave CUs empty (batches around 64 images; the 7x7 layers of a 128-image chunk):
+// a workgroup = 32 tiles x 32 couts, SIX waves (wave xi = row xi of the component grid, the same six 32x32 accumulator blocks), slabs of
+// V 18 KB + U 18 KB double buffered = 72 KB, so TWO workgroups share a CU: twice the workgroups for the same launch, the same 12 waves per
+// CU when they are all there.  Reads the same blocked U (a 32-cout half of a 64-cout block: per-lane source addresses, 512 B per component).
+constexpr int W4_US32 = 36 * 32 * 4;                 // 4608 floats
+constexpr int W4_SLAB32 = W4_VS + W4_US32;           // 9216 floats = 36 KB
+constexpr int W4_LDS32_BYTES = 2 * W4_SLAB32 * (int)sizeof(float);  // 72 KB
+constexpr int W4_THREADS32 = 384;
+
+__global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int n_nt = 2 * p.n_nt;  // 32-cout blocks
+    const int total = p.n_tb * n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, rr = total & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tb = lid / n_nt;
+    const int nt = lid - tb * n_nt;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int xi = __builtin_amdgcn_readfirstlane(t >> 6);  // wave = component row
+    const int hi = lane >> 5;
+    const int S = p.S;
+
+    const float* vsrc = p.V + (size_t)tb * S * W4_VS + lane * 4;
+    // U instruction k (0..17) moves components 2k, 2k+1: lane -> (component 2k + (lane >> 5), cout 32 (nt & 1) + (lane & 31))
+    const float* usrc = p.U + (size_t)(nt >> 1) * S * W4_US + (lane >> 5) * (W4_N * 4) + (32 * (nt & 1) + (lane & 31)) * 4;
+
+    auto issue = [&](int s, int buf) {
+        const float* sv = vsrc + (size_t)s * W4_VS;
+        const float* su = usrc + (size_t)s * W4_US;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int k = xi + 6 * i;  // 36 wave-instructions, 6 per wave
+            const float* src = (k < 18) ? sv + k * 256 : su + (k - 18) * (2 * W4_N * 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + buf * W4_SLAB32 + k * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+    const int fv = (xi * 6) * (W4_T * 4) + (lane & 31) * 4 + 2 * hi;
+    const int fu = W4_VS + (xi * 6) * (32 * 4) + (lane & 31) * 4 + 2 * hi;
+
+    issue(0, 0);
+    if (S > 1) issue(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < S; ++s) {
+        const int cur = (s & 1) * W4_SLAB32;
+        f32x2 fa[6], fb[6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) {
+            fa[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fv + nu * (W4_T * 4)]);
+            fb[nu] = *reinterpret_cast<const f32x2*>(&lds[cur + fu + nu * (32 * 4)]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), written out (see w4_gemm_kernel)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < S) issue(s + 2, s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nu = 3; nu < 6; ++nu) acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[nu][ks], fb[nu][ks], acc[nu], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+
+    // ---- output transform as w4_epilogue, 32 couts wide: exchange area [xi 6][jj 2][tile 32][cout 32] = 48 KB
+    f32x16 P[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e], a4 = acc[4][e], a5 = acc[5][e];
+        const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+        P[0][e] = a0 + s12 + s34;
+        P[1][e] = d12 + 2.f * d34;
+        P[2][e] = s12 + 4.f * s34;
+        P[3][e] = d12 + 8.f * d34 + a5;
+    }
+    const int em = t >> 3;       // gather role (threads 0 .. 255): tile within the block
+    const int eq = (t & 7) * 4;  // cout quad
+    const int n = nt * 32 + eq;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    int b = 0, ty = 0, tx = 0;
+    bool live = false;
+    if (t < 256) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        const int tg = tb * W4_T + em;
+        live = tg < p.T;
+        if (live) {
+            b = tg / p.TT;
+            const int rem = tg - b * p.TT;
+            ty = rem / p.TW;
+            tx = rem - ty * p.TW;
+        }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        if (jp) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                lds[((xi * 2 + jj) * W4_T + m) * 32 + (lane & 31)] = P[2 * jp + jj][e];
+            }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 Q[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Q[k] = *reinterpret_cast<const f32x4*>(&lds[((k * 2 + jj) * W4_T + em) * 32 + eq]);
+                const f32x4 s12 = Q[1] + Q[2], d12 = Q[1] - Q[2], s34 = Q[3] + Q[4], d34 = Q[3] - Q[4];
+                f32x4 o[4];
+                o[0] = Q[0] + s12 + s34;
+                o[1] = d12 + 2.f * d34;
+                o[2] = s12 + 4.f * s34;
+                o[3] = d12 + 8.f * d34 + Q[5];
+                const int ox = 4 * tx + 2 * jp + jj;
+                if (ox < p.W) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int oy = 4 * ty + i;
+                        if (oy < p.H) {
+                            f32x4 v = o[i] * sc + sh;
+                            if (p.relu) {
+                                v.x = fmaxf(v.x, 0.f);
+                                v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f);
+                                v.w = fmaxf(v.w, 0.f);
+                            }
+                            *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ fused input transform (56x56 / 28x28 maps)
 // The same GEMM without V in memory: the producing 1x1 convolution writes its output channel-slab major, Xs[slab of 8 ch][pixel][8]
 // (GemmArgs::y_slab8, as for wino_fused_kernel), and a workgroup owns R consecutive tile rows of the batch -- 2 x 14 tiles on the 56x56
@@ -571,6 +729,8 @@ hipError_t hpe_wino4_init_device() {
                           (const void*)w4_gemm_kernel<8>, (const void*)w4_gemm_kernel<12>})
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
 #endif
+    hipError_t e32 = hipFuncSetAttribute(reinterpret_cast<const void*>(w4_gemm32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS32_BYTES);
+    if (e32 != hipSuccess) return e32;
     hipError_t ef = hipFuncSetAttribute(reinterpret_cast<const void*>(w4_fused_kernel<56>), hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
     if (ef != hipSuccess) return ef;
     ef = hipFuncSetAttribute(reinterpret_cast<const void*>(w4_fused_kernel<28>), hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
@@ -636,12 +796,13 @@ size_t hpe_wino4_v_floats(int B, int H, int W, int C) {
 }
 
 int hpe_wino4_items(int B, int H, int W, int N) {
+    // workgroups of the launch: 32-tile x 32-cout ones (the small-launch variant) -- what the dispatch threshold counts
     const int TH = (H + 3) / 4, TW = (W + 3) / 4;
-    return (int)(((long)B * TH * TW + W4_T - 1) / W4_T) * (N / W4_N);
+    return (int)(((long)B * TH * TW + W4_T - 1) / W4_T) * (N / 32);
 }
 
 hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
-                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st) {
+                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st, int co_running) {
     if (C % 32 != 0 || N % 64 != 0 || lda % 4 != 0 || ldy % 4 != 0 || B < 1 || H < 1 || W < 1 || !x || !U || !V || !y) return hipErrorInvalidValue;
     const int TH = (H + 3) / 4, TW = (W + 3) / 4, TT = TH * TW;
     const long Tl = (long)B * TT;
@@ -688,6 +849,16 @@ hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const
         default: break;
     }
 #endif
-    hipLaunchKernelGGL(w4_gemm_kernel<0>, dim3(p.n_tb * p.n_nt), dim3(W4_THREADS), W4_LDS_BYTES, st, p);
+    // Fewer 64-cout workgroups on the device than CUs -- this launch's, times the batch chunks running beside it on other streams -- :
+    // the 32-cout variant (twice the workgroups, two per CU).  From 256 = one per CU on the 64-cout kernel is the faster one
+    // (profiles/r03/w4_n32_ab.txt).  HPE_WINO4_N32: workgroup count below which the variant is used (0 = never)
+    static const int n32_below = [] {
+        const char* e = getenv("HPE_WINO4_N32");
+        return e ? atoi(e) : 256;
+    }();
+    if (p.n_tb * p.n_nt * (co_running > 1 ? co_running : 1) < n32_below)
+        hipLaunchKernelGGL(w4_gemm32_kernel, dim3(p.n_tb * p.n_nt * 2), dim3(W4_THREADS32), W4_LDS32_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(w4_gemm_kernel<0>, dim3(p.n_tb * p.n_nt), dim3(W4_THREADS), W4_LDS_BYTES, st, p);
     return hipGetLastError();
 }

@@ -340,7 +340,8 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     if (flags & CONV_IN_SLAB8)
         return hpe_launch_wino_fused_conv3(x, L.wino_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
     if (wino_v && !res && use_wino4(c, idx, B))
-        return hpe_launch_wino4_conv3(x, s.cin, L.wino4_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st);
+        return hpe_launch_wino4_conv3(x, s.cin, L.wino4_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st,
+                                      (flags & CONV_CONCURRENT) ? c->n_streams : 1);
     // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
     // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
     if (L.wino_u && wino_v && !res && s.cin >= c->wino_min_c &&

@@ -59,12 +59,13 @@ int hpe_wino_fused_items(int B, int H, int W, int N);  // work items of that lau
 hipError_t hpe_launch_nhwc_to_slab8(const float* x, float* xs, long M, int C, hipStream_t st);
 
 // conv_wino4.hip: the same convolution as Winograd F(4x4,3x3); U = G g G^T blocked [N/64][C/4][36][64][4], V workspace of
-// hpe_wino4_v_floats(B, H, W, C) floats (blocked [tiles/32][C/4][36][32][4]); C % 32 == 0, N % 64 == 0
+// hpe_wino4_v_floats(B, H, W, C) floats (blocked [tiles/32][C/4][36][32][4]); C % 32 == 0, N % 64 == 0; co_running = batch chunks
+// launching the same layer on other streams at the same time (picks between the 64- and the 32-cout GEMM)
 size_t hpe_wino4_v_floats(int B, int H, int W, int C);
 int hpe_wino4_items(int B, int H, int W, int N);  // workgroups of the GEMM launch
 hipError_t hpe_wino4_init_device();
 hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
-                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st);
+                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st, int co_running = 1);
 
 // fused-transform F(4x4,3x3) (56x56 / 28x28 maps): xs is channel-slab major [C/8][B*H*W][8] (GemmArgs::y_slab8 of the producer)
 hipError_t hpe_launch_wino4_fused_conv3(const float* xs, const float* U, const float* scale, const float* shift, const float* zero16, float* y,
