@@ -333,7 +333,9 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_streamk_kernel(WinoArgs p) {
                                                      ((unsigned long long)__float_as_uint(acc[c][i][j][2 * qd + 1]) << 32);
                         __hip_atomic_store(&my_ws[(((c * 2 + i) * 2 + j) * 8 + qd) * 512], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): this wave's stores are acknowledged
+        // every wave's parked stores must be acknowledged before the counter / flag moves: written out, because hipcc emits no
+        // vmcnt wait for a workgroup-scope release fence or __syncthreads() here (checked in the ISA)
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
         __syncthreads();
         if (t == 0) __hip_atomic_store(p.flags + lid, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u += S - k_first;
