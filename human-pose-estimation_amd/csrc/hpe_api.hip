@@ -127,6 +127,7 @@ struct TileKnobs {
     int concurrent_tiles = 0;      // HPE_CONCURRENT_TILES=1: the tile rule of concurrent chunk launches on every launch (profiling passes with HPE_STREAMS=1)
     int wide128_min_tiles = 384;  // HPE_WIDE128_MIN_TILES: 1.5 tiles per CU (0 = the round-1 rule everywhere)
     int force_expand = -1;   // HPE_EXPAND_TILE: fp32 tile of the identity-block expand layers (experiment knob)
+    int expand_small_grid = 128;  // HPE_EXPAND_SMALL_GRID: expand layers with fewer 128x64 tiles than this take the 64x64 split-K tile (0 = never)
     int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
     int bf16_rules = 1;      // HPE_BF16_RULES=0: the round-1 tile rule (128x128 / 64x128 by grid size, double buffer)
     int bf16_p8 = 0;         // HPE_BF16_P8: layer kinds that take the 256 x 256 phase-interleaved kernel (bit mask, see pick_bf16)
@@ -246,7 +247,12 @@ int upload(hpe_ctx* c, float** p, const std::vector<float>& h) {
 int pick_tile(const TileKnobs& kn, int M, int N, int K, bool residual_expand = false, bool concurrent = false) {
     // prefer the largest tile that still gives >= 2 workgroups per CU; N == 64 layers use 64-wide tiles
     const bool wide = N > 64;
-    if (wide && residual_expand) return kn.force_expand >= 0 ? kn.force_expand : TILE_128x64_W8;
+    // identity-block expand layers: 8 waves (see below) -- unless the grid is so small that the launch is DMA latency: then the 4-wave
+    // 64x64 tile, which the launcher cuts along K (single frames: res5*_branch2c 21 -> 9 us)
+    if (wide && residual_expand) {
+        if (kn.force_expand >= 0) return kn.force_expand;
+        return (long)((M + 127) / 128) * ((N + 63) / 64) < kn.expand_small_grid ? TILE_64x64 : TILE_128x64_W8;
+    }
     if (wide && kn.force_wide >= 0) return kn.force_wide;
     if (!wide && kn.force_narrow >= 0) return kn.force_narrow;
     // Measured on MI355X (profiles/r01/d_tile_sweep.txt): with LDS-DMA staging the small tiles with 3-5 workgroups
@@ -856,6 +862,8 @@ static int finalize_impl(hpe_ctx* c) {
         c->knobs.force_bf16 = e ? atoi(e) : -1;
         e = getenv("HPE_EXPAND_TILE");
         c->knobs.force_expand = e ? atoi(e) : -1;
+        e = getenv("HPE_EXPAND_SMALL_GRID");
+        if (e) c->knobs.expand_small_grid = atoi(e);
         e = getenv("HPE_NS_BF16");
         c->knobs.force_ns_bf16 = e ? atoi(e) : -1;
         e = getenv("HPE_BF16_RULES");
