@@ -113,6 +113,11 @@ struct W4Args {
     int S;           // k-slabs (C / 4)
     int n_tb, n_nt;  // tile blocks, cout blocks
     int ldy, relu;
+    // w4_gemm32_kernel only: the C axis cut into ksplit parts (1 = whole), one workgroup each; partial outputs meet in split_ws
+    // ([output block][part][W4_SPLIT_BLOCK floats]), the part that finishes last (split_cnt, self-resetting) adds them in part order
+    int ksplit;
+    float* split_ws;
+    unsigned* split_cnt;
 };
 
 // output transform of one workgroup's 32-tile x 64-cout block: (.) A in registers, A^T (.) across the six waves of a cout half through
@@ -308,13 +313,17 @@ constexpr int W4_US32 = 36 * 32 * 4;                 // 4608 floats
 constexpr int W4_SLAB32 = W4_VS + W4_US32;           // 9216 floats = 36 KB
 constexpr int W4_LDS32_BYTES = 2 * W4_SLAB32 * (int)sizeof(float);  // 72 KB
 constexpr int W4_THREADS32 = 384;
+constexpr int W4_SPLIT_BLOCK = 32 * 16 * 32;  // floats of one workgroup's output block (32 tiles x 16 pixels x 32 couts)
+constexpr int W4_SPLIT_SLOTS = 256;           // parked blocks the workspace holds (16 MB) = workgroups of a split launch
 
 __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int n_nt = 2 * p.n_nt;  // 32-cout blocks
     const int total = p.n_tb * n_nt;
-    const int bid = blockIdx.x;
+    const int KS = p.ksplit;
+    const int bid = KS > 1 ? (int)blockIdx.x / KS : (int)blockIdx.x;
+    const int part = KS > 1 ? (int)blockIdx.x - bid * KS : 0;
     const int xcd = bid & 7;
     const int q = total >> 3, rr = total & 7;
     const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
     const int xi = __builtin_amdgcn_readfirstlane(t >> 6);  // wave = component row
     const int hi = lane >> 5;
     const int S = p.S;
+    const int s_begin = (int)((long)part * S / KS), s_end = (int)((long)(part + 1) * S / KS);  // this workgroup's slabs
 
     const float* vsrc = p.V + (size_t)tb * S * W4_VS + lane * 4;
     // U instruction k (0..17) moves components 2k, 2k+1: lane -> (component 2k + (lane >> 5), cout 32 (nt & 1) + (lane & 31))
@@ -351,14 +361,14 @@ __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
     const int fv = (xi * 6) * (W4_T * 4) + (lane & 31) * 4 + 2 * hi;
     const int fu = W4_VS + (xi * 6) * (32 * 4) + (lane & 31) * 4 + 2 * hi;
 
-    issue(0, 0);
-    if (S > 1) issue(1, 1);
+    issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int s = 0; s < S; ++s) {
-        const int cur = (s & 1) * W4_SLAB32;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int cur = ((s - s_begin) & 1) * W4_SLAB32;
         f32x2 fa[6], fb[6];
 #pragma unroll
         for (int nu = 0; nu < 6; ++nu) {
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 2 < S) issue(s + 2, s & 1);
+        if (s + 2 < s_end) issue(s + 2, (s - s_begin) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -413,6 +423,9 @@ __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
             tx = rem - ty * p.TW;
         }
     }
+    auto pack2 = [](float a, float b) { return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32); };
+    unsigned long long* ws_block = reinterpret_cast<unsigned long long*>(p.split_ws) + (size_t)lid * KS * (W4_SPLIT_BLOCK / 2) + (t & 255);
+    unsigned long long* ws_mine = ws_block + (size_t)part * (W4_SPLIT_BLOCK / 2);
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         if (jp) __syncthreads();
@@ -437,7 +450,15 @@ __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
                 o[2] = s12 + 4.f * s34;
                 o[3] = d12 + 8.f * d34 + Q[5];
                 const int ox = 4 * tx + 2 * jp + jj;
-                if (ox < p.W) {
+                if (KS > 1) {
+                    // a part of the C axis: park the partial outputs (relaxed agent-scope atomics = sc1 stores, see conv_wino.hip)
+                    unsigned long long* w = ws_mine + (size_t)((jp * 2 + jj) * 4) * 2 * 256;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __hip_atomic_store(w + (2 * i) * 256, pack2(o[i].x, o[i].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(w + (2 * i + 1) * 256, pack2(o[i].z, o[i].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else if (ox < p.W) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int oy = 4 * ty + i;
@@ -455,6 +476,52 @@ __global__ __launch_bounds__(W4_THREADS32, 2) void w4_gemm32_kernel(W4Args p) {
                 }
             }
         }
+    }
+    if (KS > 1) {
+        // every wave's parked stores must be acknowledged before the counter moves (written out: hipcc emits no vmcnt wait for a
+        // workgroup-scope fence / __syncthreads() here)
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(lds);
+        if (t == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.split_cnt + lid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(KS - 1);
+            if (last) __hip_atomic_store(p.split_cnt + lid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch / graph replay
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag || !live) return;
+        // last part of this output block: add the parts in part order (bitwise the same result whichever part is last), BN, ReLU, store
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int ox = 4 * tx + 2 * jp + jj;
+                if (ox >= p.W) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int oy = 4 * ty + i;
+                    if (oy >= p.H) continue;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    for (int k = 0; k < KS; ++k) {
+                        const unsigned long long* w = ws_block + (size_t)k * (W4_SPLIT_BLOCK / 2) + (size_t)(((jp * 2 + jj) * 4 + i) * 2) * 256;
+                        const unsigned long long lo = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long hi2 = __hip_atomic_load(w + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.x += __uint_as_float((unsigned)lo);
+                        a.y += __uint_as_float((unsigned)(lo >> 32));
+                        a.z += __uint_as_float((unsigned)hi2);
+                        a.w += __uint_as_float((unsigned)(hi2 >> 32));
+                    }
+                    f32x4 v = a * sc + sh;
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.H + oy) * p.W + ox) * p.ldy + n) = v;
+                }
+            }
     }
 }
 
@@ -723,6 +790,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void w4_fused_kernel(W4FusedArgs p) 
 }  // namespace
 
 // hipFuncSetAttribute applies to the CURRENT device: hpe_finalize calls this once per ctx under its device guard
+size_t hpe_wino4_split_ws_floats() { return (size_t)W4_SPLIT_SLOTS * W4_SPLIT_BLOCK + W4_SPLIT_SLOTS; }
+
 hipError_t hpe_wino4_init_device() {
 #ifdef HPE_ABLATION
     for (const void* f : {(const void*)w4_gemm_kernel<1>, (const void*)w4_gemm_kernel<2>, (const void*)w4_gemm_kernel<3>, (const void*)w4_gemm_kernel<4>,
@@ -802,7 +871,7 @@ int hpe_wino4_items(int B, int H, int W, int N) {
 }
 
 hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
-                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st, int co_running) {
+                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st, int co_running, float* split_ws) {
     if (C % 32 != 0 || N % 64 != 0 || lda % 4 != 0 || ldy % 4 != 0 || B < 1 || H < 1 || W < 1 || !x || !U || !V || !y) return hipErrorInvalidValue;
     const int TH = (H + 3) / 4, TW = (W + 3) / 4, TT = TH * TW;
     const long Tl = (long)B * TT;
@@ -856,9 +925,32 @@ hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const
         const char* e = getenv("HPE_WINO4_N32");
         return e ? atoi(e) : 256;
     }();
-    if (p.n_tb * p.n_nt * (co_running > 1 ? co_running : 1) < n32_below)
-        hipLaunchKernelGGL(w4_gemm32_kernel, dim3(p.n_tb * p.n_nt * 2), dim3(W4_THREADS32), W4_LDS32_BYTES, st, p);
-    else
+    p.ksplit = 1;
+    if (p.n_tb * p.n_nt * (co_running > 1 ? co_running : 1) < n32_below) {
+        // Still fewer workgroups than half the CUs, and a long C axis (the 7x7 layers up to ~64 images: 128 slabs = a 0.14 ms chain of
+        // barriers whatever the batch): cut C into 2-4 parts of >= 16 slabs.  Needs a workspace that no concurrent launch uses (the caller
+        // passes one per chunk stream).  HPE_WINO4_KSPLIT=0: never; HPE_WINO4_KSPLIT_WGS: workgroups on the device to aim for.
+        static const int ksplit_on = [] {
+            const char* e = getenv("HPE_WINO4_KSPLIT");
+            return e ? atoi(e) : 1;
+        }();
+        static const int ksplit_wgs = [] {
+            const char* e = getenv("HPE_WINO4_KSPLIT_WGS");
+            return e ? atoi(e) : 512;  // two 6-wave workgroups per CU
+        }();
+        const int wgs = p.n_tb * p.n_nt * 2 * (co_running > 1 ? co_running : 1);  // on the device, with the co-running chunks' launches
+        if (split_ws && ksplit_on && 2 * wgs <= ksplit_wgs) {
+            int ks = ksplit_wgs / wgs;
+            if (ks > 4) ks = 4;
+            while (ks > 1 && (p.S / ks < 16 || p.n_tb * p.n_nt * 2 * ks > W4_SPLIT_SLOTS)) --ks;
+            if (ks > 1) {
+                p.ksplit = ks;
+                p.split_ws = split_ws;
+                p.split_cnt = reinterpret_cast<unsigned*>(split_ws + (size_t)W4_SPLIT_SLOTS * W4_SPLIT_BLOCK);
+            }
+        }
+        hipLaunchKernelGGL(w4_gemm32_kernel, dim3(p.n_tb * p.n_nt * 2 * p.ksplit), dim3(W4_THREADS32), W4_LDS32_BYTES, st, p);
+    } else
         hipLaunchKernelGGL(w4_gemm_kernel<0>, dim3(p.n_tb * p.n_nt), dim3(W4_THREADS), W4_LDS_BYTES, st, p);
     return hipGetLastError();
 }

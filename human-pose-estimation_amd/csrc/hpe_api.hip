@@ -180,7 +180,7 @@ struct hpe_ctx {
     int wino_fused_min_hw = 28;  // smallest map side on the fused path (HPE_WINO_FUSED_MINHW)
     int dual_gemm = 1;        // conv_block: branch2c + branch1 in one launch (HPE_DUAL=0: two launches through the shortcut buffer)
     int stem_fused = 1;       // conv1 + BN + ReLU + max-pool as one kernel reading the raw images (HPE_STEM_FUSED=0: pad / im2col GEMM / pool)
-    int wino4_min_items = 128;  // F(4x4) launches need at least this many workgroups (HPE_WINO4_MIN_ITEMS), else F(2x2) / direct by their rules
+    int wino4_min_items = 64;  // F(4x4) launches need at least this many 32-cout workgroups (HPE_WINO4_MIN_ITEMS), else F(2x2) / direct by their rules
     int wino4_fused = 0;      // map sizes (bits as wino_f4: 4 = 28x28, 8 = 56x56) whose F(4x4) layers take the fused-transform kernel (HPE_WINO4_FUSED)
     int wino_f4 = 0;          // map sizes whose 3x3 layers run as Winograd F(4x4,3x3): bit 0: 7x7, 1: 14x14, 2: 28x28, 3: 56x56 (HPE_WINO_F4)
     int mesh_a2b = 0;         // pixel -> vertex search of the mesh loss: 0 cell grid, 1 VALU full search, 2 matrix-core full search
@@ -199,6 +199,7 @@ struct hpe_ctx {
     bool tail_pending = false;
     unsigned pipe_idx = 0;
     float* feat_alt = nullptr;
+    float* w4_split = nullptr;  // F(4x4) C-axis split workspaces + counters (4 x hpe_wino4_split_ws_floats: one per chunk-stream slot)
     float* partial_tail = nullptr;
     size_t partial_tail_floats = 0;
     bool dense_on_tail = false;  // set while a pipelined tail is being enqueued: run_dense then uses partial_tail
@@ -347,7 +348,8 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         return hpe_launch_wino_fused_conv3(x, L.wino_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
     if (wino_v && !res && use_wino4(c, idx, B))
         return hpe_launch_wino4_conv3(x, s.cin, L.wino4_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st,
-                                      (flags & CONV_CONCURRENT) ? c->n_streams : 1);
+                                      (flags & CONV_CONCURRENT) ? c->n_streams : 1,
+                                      c->w4_split && slot >= 0 && slot < 4 ? c->w4_split + (size_t)slot * hpe_wino4_split_ws_floats() : nullptr);
     // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
     // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
     if (L.wino_u && wino_v && !res && s.cin >= c->wino_min_c &&
@@ -1134,6 +1136,12 @@ static int finalize_impl(hpe_ctx* c) {
         }
         if (c->have_encoder && !c->bf16 && c->wino_min_c > 0) {
             if ((rc = dev_alloc(c, &c->wino_v, B * WINO_V_PITCH + WINO_V_SLACK, false))) return rc;
+            if (c->wino_f4) {
+                // one workspace per chunk-stream slot (16 MB each), block counters zeroed
+                const size_t nws = hpe_wino4_split_ws_floats();
+                if ((rc = dev_alloc(c, &c->w4_split, 4 * nws, false))) return rc;
+                for (int k = 0; k < 4; ++k) HIP_TRY(hipMemset(c->w4_split + (k + 1) * nws - 256, 0, 256 * sizeof(unsigned)));
+            }
             // persistent stream-K scheduling of the Winograd GEMM: opt-in.  It removes the partial last round of workgroups
             // (-7 % on a res4 layer, -2 % on the step with HPE_STREAMS=1) but with the default batch-chunk streams, whose
             // kernels already fill those idle CUs, the step time is unchanged within noise (profiles/r01/g_wino_streamk.txt)

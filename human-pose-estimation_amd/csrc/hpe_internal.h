@@ -65,7 +65,10 @@ size_t hpe_wino4_v_floats(int B, int H, int W, int C);
 int hpe_wino4_items(int B, int H, int W, int N);  // workgroups of the GEMM launch
 hipError_t hpe_wino4_init_device();
 hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const float* scale, const float* shift, float* y, int ldy, int B,
-                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st, int co_running = 1);
+                                  int H, int W, int C, int N, int relu, float* V, hipStream_t st, int co_running = 1, float* split_ws = nullptr);
+// split_ws: hpe_wino4_split_ws_floats() floats whose LAST 256 (unsigned counters) are zero, owned by launches that are alone on the device
+// (nullptr: the C axis is never cut)
+size_t hpe_wino4_split_ws_floats();
 
 // fused-transform F(4x4,3x3) (56x56 / 28x28 maps): xs is channel-slab major [C/8][B*H*W][8] (GemmArgs::y_slab8 of the producer)
 hipError_t hpe_launch_wino4_fused_conv3(const float* xs, const float* U, const float* scale, const float* shift, const float* zero16, float* y,
