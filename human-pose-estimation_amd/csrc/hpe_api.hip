@@ -188,7 +188,7 @@ struct hpe_ctx {
     unsigned long long* loss_counter = nullptr;  // hpe_debug_set_loss_counter
     int wino_fused = 1;       // 56x56 / 28x28 maps: input transform inside the GEMM kernel, fed by a slab-major 1x1 producer
     hipStream_t aux[3]{};
-    int min_chunk = 44;  // HPE_MIN_CHUNK: smallest batch chunk that still gets its own stream
+    int min_chunk = 32;  // HPE_MIN_CHUNK: smallest batch chunk that still gets its own stream
     hipEvent_t ev_fork{}, ev_join[3]{};
     // software pipeline across calls (hpe_forward_pipelined): the regressor + SMPL tail of batch k runs on `tail_st` while the
     // caller's stream already runs the encoder of batch k+1; features alternate between two buffers, the Dense layers of the tail
@@ -573,9 +573,10 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
 // back-to-back launches on one stream and therefore runs unchunked.
 hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features, int ldfeat, hipStream_t st) {
     int nstream = c->n_streams;
-    // a chunk needs >= 44 images to keep its own launches efficient (round 1: B = 64 is 7 % faster unchunked, B = 128 best with 2
-    // chunks, B = 256 equal for 2-4, profiles/r01/g_wino_chunk_rule.txt; round 2: B = 72 / 80 unchunked 15.1 / 15.2 k img/s against
-    // 14.6 k in two chunks, B = 88 / 96 / 112 in two chunks 15.3 / 15.4 / 15.6 k against 14.3 / 14.8 / 15.3 k unchunked)
+    // a chunk needs >= 32 images to keep its own launches efficient.  Rounds 1-2 had 44 (B = 64 was 7 % faster unchunked,
+    // profiles/r01/g_wino_chunk_rule.txt); with the 32-cout / C-split F(4x4) launches of round 3 two chunks of 32-40 win: B = 64 / 72 / 80
+    // 15.0 / 15.1 / 15.8 k img/s in two chunks against 14.1 / 13.4 / 14.1 k unchunked, B = 56 13.3 against 13.6 k, B = 40 12.5 against
+    // 12.8 k (profiles/r03/chunk_rule.txt); B = 128 best with 2 chunks, B = 256 equal for 2-3, 4 chunks of 64 lose 5 %
     if (nstream > B / c->min_chunk) nstream = B / c->min_chunk;
     if (c->timing >= 2 || nstream < 2) nstream = 1;
     if (nstream == 1) return encoder_chunk(c, images, 0, B, features, ldfeat, st);
@@ -1194,8 +1195,8 @@ static int finalize_impl(hpe_ctx* c) {
         if (ns > 4) ns = 4;
         c->n_streams = ns;
         // bf16 launches are short enough to leave CUs idle at small batches: two chunks pay from 2 x 24 images on (B = 48 / 64 / 80:
-        // 38.5 / 44.8 / 48.9 k img/s against 34.7 / 39.2 / 44.5 k as one chunk); fp32 from 2 x 44 (see encoder_impl)
-        c->min_chunk = c->bf16 ? 24 : 44;
+        // 38.5 / 44.8 / 48.9 k img/s against 34.7 / 39.2 / 44.5 k as one chunk); fp32 from 2 x 32 (see encoder_impl)
+        c->min_chunk = c->bf16 ? 24 : 32;
         e = getenv("HPE_MIN_CHUNK");
         if (e && atoi(e) >= 8) c->min_chunk = atoi(e);
         e = getenv("HPE_CHUNK");
