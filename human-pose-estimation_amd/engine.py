@@ -467,9 +467,10 @@ class HpeEngine(object):
     def encoder_kernel_description(self):
         """The kernel family bench.py's `roofline` block prices (one string per encoder dtype, kept next to the dispatch)."""
         if self.encoder_dtype == "fp32":
-            return ("conv_gemm_f32_dma_kernel (the 1x1 / strided / dual-source layers and the 56x56 3x3 layers) + w4_input_kernel + "
-                    "w4_gemm_kernel (the 13 3x3 layers on the 28x28 / 14x14 / 7x7 maps as fp32 Winograd F(4x4,3x3); F(2x2,3x3) / direct "
-                    "below 128 work items) -- the 53 conv layers of one step, priced at their direct-convolution FLOPs")
+            return ("conv_gemm_f32_dma_kernel (the 1x1 / strided / dual-source layers) + w4_input_kernel + w4_gemm_kernel / w4_gemm32_kernel "
+                    "(the 13 3x3 layers on the 28x28 / 14x14 / 7x7 maps as fp32 Winograd F(4x4,3x3); F(2x2,3x3) / direct below 64 work "
+                    "items) + wino_fused_kernel (the three 56x56 3x3 layers, F(2x2,3x3)) + stem_fused_f32_kernel -- the 53 conv layers of one "
+                    "step, priced at their direct-convolution FLOPs")
         return "conv_gemm_bf16_dma_kernel -- the 53 conv layers of one step, priced at their algorithmic HBM bytes"
 
     def enable_timing(self, level=1):
