@@ -486,9 +486,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
 // makes every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row.
 // Epilogue shared by the DMA kernel and the split-K fix-up kernel: BN scale/shift in registers, transpose through LDS,
 // rows leave as 16 B per lane with the residual read the same way.
-template <int BM, int BN, int WM, int WN>
+// rpre (use_pre): the residual vectors of this thread's rows, loaded by the caller before its main loop (else they are read here)
+template <int BM, int BN, int WM, int WN, int NP>
 __device__ __forceinline__ void conv_epilogue(const GemmArgs& p, float* lds, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0, int t,
-                                              int lane, int wm, int wn) {
+                                              int lane, int wm, int wn, const f32x4 (&rpre)[NP], bool use_pre) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
     constexpr int NTHR = 64 * WM * WN;
@@ -519,14 +520,15 @@ __device__ __forceinline__ void conv_epilogue(const GemmArgs& p, float* lds, f32
         const int c4 = (t - r * TPR) * 4;
         const int n = n0 + c4;
         const bool full = (n + 3) < p.N;
-#pragma unroll 4
+#pragma unroll
         for (int pass = 0; pass < BM / RPP; ++pass) {
             const int row = pass * RPP + r;
             const int m = m0 + row;
             if (m >= p.M || n >= p.N) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * EP + c4]);
             if (full) {
-                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n);
+                if (use_pre) v += rpre[pass < NP ? pass : 0];
+                else if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n);
                 if (p.relu) {
                     v.x = fmaxf(v.x, 0.f);
                     v.y = fmaxf(v.y, 0.f);
@@ -640,6 +642,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Residual rows of the epilogue, fetched NOW (8-wave tiles = the identity-block expand layers, which are all epilogue: 4 x 16 B per
+    // thread): their HBM latency runs beside the operand DMA and the MFMAs instead of after the LDS transpose.
+    constexpr int R_TPR = BN / 4, R_RPP = NTHR / R_TPR, R_NPASS = BM / R_RPP;
+    constexpr bool R_PRE = (NW == 8) && R_NPASS <= 4;
+    f32x4 rpre[R_PRE ? R_NPASS : 1];
+    bool r_pre = false;
+    if constexpr (R_PRE) {
+        const int rr_ = t / R_TPR;
+        const int n = n0 + (t - rr_ * R_TPR) * 4;
+        r_pre = p.res != nullptr && p.res_prefetch && part < 0 && (n + 3) < p.N;
+        if (r_pre) {
+#pragma unroll
+            for (int pass = 0; pass < R_NPASS; ++pass) {
+                const int m = m0 + pass * R_RPP + rr_;
+                rpre[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(m < p.M ? m : p.M - 1) * p.ldres + n);
+            }
+        }
+    }
+
     SlabPos sp = slab_seek<MODE>(p, ks0);
 
     auto issue_dma = [&](int slab, int buf) {
@@ -708,7 +729,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
                 }
         return;
     }
-    conv_epilogue<BM, BN, WM, WN>(p, lds, acc, m0, n0, t, lane, wm, wn);
+    conv_epilogue<BM, BN, WM, WN>(p, lds, acc, m0, n0, t, lane, wm, wn, rpre, R_PRE && r_pre);
 }
 
 // Reduces the K-slices of every tile (fixed order -> bitwise reproducible) and runs the normal epilogue.
@@ -749,7 +770,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_fixup_kernel(GemmArgs 
                     acc[i][j][4 * qd + 3] += v.w;
                 }
     }
-    conv_epilogue<BM, BN, WM, WN>(p, lds, acc, mtile * BM, ntile * BN, t, lane, wm, wn);
+    const f32x4 no_pre[1] = {{0.f, 0.f, 0.f, 0.f}};
+    conv_epilogue<BM, BN, WM, WN>(p, lds, acc, mtile * BM, ntile * BN, t, lane, wm, wn, no_pre, false);
 }
 
 // environment knobs of the launcher: read once, in a thread-safe function-local static initialiser
@@ -785,6 +807,11 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
     const int grid = p.n_mtiles * p.n_ntiles;
     p.split_k = 1;
     if constexpr (WM * WN == 8) {
+        static const int res_prefetch = [] {
+            const char* e = getenv("HPE_RES_PREFETCH");
+            return e ? atoi(e) : 1;
+        }();
+        p.res_prefetch = res_prefetch;
         hipLaunchKernelGGL((conv_gemm_f32_dma_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(512), 0, st, p);
         return hipGetLastError();
     } else {

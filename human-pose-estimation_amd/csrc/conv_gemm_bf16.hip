@@ -127,6 +127,25 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (W
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Residual rows of the epilogue, fetched NOW (tiles with <= 4 row passes per thread: the expand layers' 128 x 64 tiles): their HBM
+    // latency runs beside the operand DMA instead of after the LDS transpose (conv_gemm.hip does the same in fp32).
+    constexpr int R_TPR = BN / 8, R_RPP = NTHR / R_TPR, R_NPASS = BM / R_RPP;
+    constexpr bool R_PRE = R_NPASS <= 4;
+    bf16x8 rpre[R_PRE ? R_NPASS : 1];
+    bool r_pre = false;
+    if constexpr (R_PRE) {
+        const int rr_ = t / R_TPR;
+        const int n = n0 + (t - rr_ * R_TPR) * 8;
+        r_pre = R != nullptr && p.res_prefetch && (n + 7) < p.N;
+        if (r_pre) {
+#pragma unroll
+            for (int pass = 0; pass < R_NPASS; ++pass) {
+                const int m = m0 + pass * R_RPP + rr_;
+                rpre[pass] = *reinterpret_cast<const bf16x8*>(R + (size_t)(m < p.M ? m : p.M - 1) * p.ldres + n);
+            }
+        }
+    }
+
     const int S = p.K / BKE;
     SlabB sp;
     sp.tap = 0;
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (W
         const int c8 = (t - r * TPR) * 8;
         const int n = n0 + c8;
         const bool full = (n + 7) < p.N;
-#pragma unroll 4
+#pragma unroll
         for (int pass = 0; pass < BM / RPP; ++pass) {
             const int row = pass * RPP + r;
             const int m = m0 + row;
@@ -240,7 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (W
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(&lds[row * EP + c8 + 4]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             if (full) {
-                if (R) {
+                if (R_PRE && r_pre) {
+                    const bf16x8 rv = rpre[pass < (R_PRE ? R_NPASS : 1) ? pass : 0];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += (float)rv[u];
+                } else if (R) {
                     const bf16x8 rv = *reinterpret_cast<const bf16x8*>(R + (size_t)m * p.ldres + n);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] += (float)rv[u];
@@ -268,6 +291,11 @@ template <int MODE, int BM, int BN, int WM, int WN, int NS>
 hipError_t launch_cfg_b(GemmArgs& p, hipStream_t st) {
     p.n_mtiles = (p.M + BM - 1) / BM;
     p.n_ntiles = (p.N + BN - 1) / BN;
+    static const int res_prefetch = [] {
+        const char* e = getenv("HPE_RES_PREFETCH");
+        return e ? atoi(e) : 1;
+    }();
+    p.res_prefetch = res_prefetch;
     hipLaunchKernelGGL((conv_gemm_bf16_dma_kernel<MODE, BM, BN, WM, WN, NS>), dim3(p.n_mtiles * p.n_ntiles), dim3(64 * WM * WN), 0, st, p);
     return hipGetLastError();
 }

@@ -30,6 +30,7 @@ struct GemmArgs {
     unsigned long long* dbg;  // diagnostics only (HPE_ABLATION builds): per-workgroup {shader clocks, 100 MHz ticks}
     const float* x2;  // GEMM_DUAL: second A source (strided NHWC)
     int k1_slabs;     // GEMM_DUAL: k-slabs taken from x
+    int res_prefetch;  // filled by the launcher: 8-wave tiles read their residual rows before the main loop (HPE_RES_PREFETCH=0: in the epilogue)
     int y_slab8;  // 1: y is written channel-slab major, y[(n / 8) * M + m][n % 8] (the layout the fused Winograd kernel reads); needs N % 8 == 0
 };
 
