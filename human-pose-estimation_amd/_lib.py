@@ -42,10 +42,11 @@ class HpeConfig(C.Structure):
         ("wino_f4", C.c_int),
         ("wino4_fused", C.c_int),
         ("bf16_p8", C.c_int),
+        ("wino4_ksplit", C.c_int),
     ]
 
 
-PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4", "wino4_fused", "bf16_p8")
+PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4", "wino4_fused", "bf16_p8", "wino4_ksplit")
 
 
 class HpeSmplModel(C.Structure):

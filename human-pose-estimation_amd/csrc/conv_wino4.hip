@@ -929,17 +929,13 @@ hipError_t hpe_launch_wino4_conv3(const float* x, int lda, const float* U, const
     if (p.n_tb * p.n_nt * (co_running > 1 ? co_running : 1) < n32_below) {
         // Still fewer workgroups than half the CUs, and a long C axis (the 7x7 layers up to ~64 images: 128 slabs = a 0.14 ms chain of
         // barriers whatever the batch): cut C into 2-4 parts of >= 16 slabs.  Needs a workspace that no concurrent launch uses (the caller
-        // passes one per chunk stream).  HPE_WINO4_KSPLIT=0: never; HPE_WINO4_KSPLIT_WGS: workgroups on the device to aim for.
-        static const int ksplit_on = [] {
-            const char* e = getenv("HPE_WINO4_KSPLIT");
-            return e ? atoi(e) : 1;
-        }();
+        // passes one per chunk stream; nullptr = plan option wino4_ksplit off).  HPE_WINO4_KSPLIT_WGS: workgroups on the device to aim for.
         static const int ksplit_wgs = [] {
             const char* e = getenv("HPE_WINO4_KSPLIT_WGS");
             return e ? atoi(e) : 512;  // two 6-wave workgroups per CU
         }();
         const int wgs = p.n_tb * p.n_nt * 2 * (co_running > 1 ? co_running : 1);  // on the device, with the co-running chunks' launches
-        if (split_ws && ksplit_on && 2 * wgs <= ksplit_wgs) {
+        if (split_ws && 2 * wgs <= ksplit_wgs) {
             int ks = ksplit_wgs / wgs;
             if (ks > 4) ks = 4;
             while (ks > 1 && (p.S / ks < 16 || p.n_tb * p.n_nt * 2 * ks > W4_SPLIT_SLOTS)) --ks;

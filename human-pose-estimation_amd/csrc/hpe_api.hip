@@ -199,6 +199,7 @@ struct hpe_ctx {
     bool tail_pending = false;
     unsigned pipe_idx = 0;
     float* feat_alt = nullptr;
+    int wino4_ksplit = 1;  // plan option wino4_ksplit / HPE_WINO4_KSPLIT
     float* w4_split = nullptr;  // F(4x4) C-axis split workspaces + counters (4 x hpe_wino4_split_ws_floats: one per chunk-stream slot)
     float* partial_tail = nullptr;
     size_t partial_tail_floats = 0;
@@ -665,7 +666,7 @@ void hpe_config_init(HpeConfig* cfg) {
     cfg->bn_eps = 1e-3f;
     cfg->encoder_dtype = 0;
     cfg->n_streams = cfg->dual_gemm = cfg->stem_fused = cfg->wino_min_c = cfg->wino_min_items = cfg->wino_fused = -1;
-    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = -1;
+    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = cfg->wino4_ksplit = -1;
 }
 
 int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
@@ -847,6 +848,7 @@ static int finalize_impl(hpe_ctx* c) {
         // 18,540; the 56x56 maps lose: their V round trip costs more than the direct kernel's extra multiplies)
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
+        c->wino4_ksplit = opt(c->cfg.wino4_ksplit, "HPE_WINO4_KSPLIT", 1);
         c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
@@ -1137,7 +1139,7 @@ static int finalize_impl(hpe_ctx* c) {
         }
         if (c->have_encoder && !c->bf16 && c->wino_min_c > 0) {
             if ((rc = dev_alloc(c, &c->wino_v, B * WINO_V_PITCH + WINO_V_SLACK, false))) return rc;
-            if (c->wino_f4) {
+            if (c->wino_f4 && c->wino4_ksplit) {
                 // one workspace per chunk-stream slot (16 MB each), block counters zeroed
                 const size_t nws = hpe_wino4_split_ws_floats();
                 if ((rc = dev_alloc(c, &c->w4_split, 4 * nws, false))) return rc;

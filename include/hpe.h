@@ -76,6 +76,8 @@ typedef struct HpeConfig {
     int bf16_p8;           /* HPE_BF16_P8          bf16 layer kinds on the 256 x 256 phase-interleaved GEMM kernel (N % 256 == 0, K >= 512 only):
                             *                      1 the 3x3 layers of stage 4, 2 those of stage 5, 4 1x1 / strided layers, 8 the dual-source
                             *                      launch of res5a, 16 the other dual-source launches */
+    int wino4_ksplit;      /* HPE_WINO4_KSPLIT     small F(4x4) launches cut their channel axis into 2-4 parts that are added in part order
+                            *                      (1); 0 = never (one summation order per output whatever the batch) */
 } HpeConfig;
 
 /* defaults: device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1 */

@@ -306,6 +306,23 @@ def test_winograd4_encoder_features(engine_wino4, engines_direct_and_wino, asset
     assert rel(fw, ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,streams", [(32, 1), (64, 1), (64, 2), (128, 2)])
+def test_winograd4_channel_split_equals_unsplit(assets, B, streams):
+    """Small F(4x4) launches cut their channel axis into 2-4 workgroup parts whose partial output blocks meet in a per-stream workspace
+    (plan option wino4_ksplit): same features as a context that never splits, to the rounding of the different summation order;
+    bitwise repeatable (the last part adds the parts in part order), also with two chunk streams sharing the device."""
+    img = gpu(synthetic.make_images(B, seed=31))
+    off = encoder_engine(assets, B, wino4_ksplit=0, n_streams=streams)
+    on = encoder_engine(assets, B, wino4_ksplit=1, n_streams=streams)
+    f0 = cpu(off.encoder(img))
+    f1 = cpu(on.encoder(img))
+    assert rel(f1, f0) < 5e-6, rel(f1, f0)
+    for _ in range(4):
+        assert np.array_equal(cpu(on.encoder(img)), f1)
+    off.close()
+    on.close()
+
+
 @pytest.mark.parametrize("B,streams,fused", [(100, 1, 0), (256, 2, 0), (256, 2, 12)])
 def test_winograd4_full_size_equals_direct(assets, B, streams, fused):
     """Metric-size launches (200 ... 512 workgroups of the F(4x4) GEMM in flight, one or two chunk streams): features and two layers
