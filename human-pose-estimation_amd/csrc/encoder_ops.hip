@@ -76,6 +76,27 @@ __global__ void avgpool_kernel(const f32x4* __restrict__ x, float* __restrict__ 
     *reinterpret_cast<f32x4*>(y + (long)b * ldy + c * 4) = o;
 }
 
+// The same for small batches (the latency path): 8 threads share a channel quad, each adds every 8th pixel (independent loads in
+// flight instead of a chain of HW dependent ones: 13 -> 4 us for one image), shuffle reduction in the fixed order of the xor tree.
+__global__ __launch_bounds__(256) void avgpool_small_kernel(const f32x4* __restrict__ x, float* __restrict__ y, int B, int HW, int C4, int ldy) {
+    const int q = blockIdx.x * 32 + (threadIdx.x >> 3);  // (image, channel quad)
+    const int kg = threadIdx.x & 7;
+    const bool ok = q < B * C4;
+    const int c = ok ? q % C4 : 0;
+    const int b = ok ? q / C4 : 0;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* p = x + (long)b * HW * C4 + c;
+#pragma unroll 8
+    for (int k = kg; k < HW; k += 8) s += p[(long)k * C4];
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        s.x += __shfl_xor(s.x, off, 64);
+        s.y += __shfl_xor(s.y, off, 64);
+        s.z += __shfl_xor(s.z, off, 64);
+        s.w += __shfl_xor(s.w, off, 64);
+    }
+    if (ok && kg == 0) *reinterpret_cast<f32x4*>(y + (long)b * ldy + c * 4) = s * (1.0f / (float)HW);
+}
 
 // Dense layer for very small batches (M <= 4; from M = 8 on the split-K GEMM + fix-up pair is faster again): y[m][n] = act((x[m,:] . Wt[n,:]) * scale[n] + shift[n] + res[m][n]).
 // One wave per output column n (a contiguous K-float row of the packed weights, read once, 16 B per lane), all M rows of x at
@@ -159,6 +180,10 @@ hipError_t hpe_launch_maxpool(const float* x, float* y, int B, int H, int C, hip
 hipError_t hpe_launch_avgpool(const float* x, float* y, int B, int HW, int C, int ldy, hipStream_t st) {
     if ((C % 4) != 0 || (ldy % 4) != 0) return hipErrorInvalidValue;
     const int total = B * (C / 4);
+    if (B <= 16) {
+        hipLaunchKernelGGL(avgpool_small_kernel, dim3((total + 31) / 32), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), y, B, HW, C / 4, ldy);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), y, B, HW,
                        C / 4, ldy);
     return hipGetLastError();
