@@ -200,6 +200,7 @@ struct hpe_ctx {
     unsigned pipe_idx = 0;
     float* feat_alt = nullptr;
     int wino4_ksplit = 1;  // plan option wino4_ksplit / HPE_WINO4_KSPLIT
+    int co_running = 1;    // chunk streams of the encoder call being enqueued (launch-size rules of the F(4x4) kernels)
     float* w4_split = nullptr;  // F(4x4) C-axis split workspaces + counters (4 x hpe_wino4_split_ws_floats: one per chunk-stream slot)
     float* partial_tail = nullptr;
     size_t partial_tail_floats = 0;
@@ -349,7 +350,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         return hpe_launch_wino_fused_conv3(x, L.wino_u, L.scale, L.shift, c->zeros, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, st);
     if (wino_v && !res && use_wino4(c, idx, B))
         return hpe_launch_wino4_conv3(x, s.cin, L.wino4_u, L.scale, L.shift, y, s.cout, B, s.hin, s.hin, s.cin, s.cout, relu, wino_v, st,
-                                      (flags & CONV_CONCURRENT) ? c->n_streams : 1,
+                                      (flags & CONV_CONCURRENT) ? c->co_running : 1,
                                       c->w4_split && slot >= 0 && slot < 4 ? c->w4_split + (size_t)slot * hpe_wino4_split_ws_floats() : nullptr);
     // Winograd needs enough (64-tile x 64-cout) work items to occupy the 256 CUs (one 8-wave workgroup each); below that
     // the direct kernel with split-K is faster (measured crossover: batch ~32, profiles/r01/g_wino_small_batch.txt)
@@ -593,13 +594,19 @@ hipError_t encoder_impl(hpe_ctx* c, const float* images, int B, float* features,
     nchunk = (B + per - 1) / per;
     HIPE(hipEventRecord(c->ev_fork, st));
     for (int k = 1; k < nstream; ++k) HIPE(hipStreamWaitEvent(c->aux[k - 1], c->ev_fork, 0));
+    c->co_running = nstream;
     for (int k = 0; k < nchunk; ++k) {
         const int i0 = k * per;
         const int n = (i0 + per <= B) ? per : (B - i0);
         const int sid = k % nstream;
         hipStream_t s = (sid == 0) ? st : c->aux[sid - 1];
-        HIPE(encoder_chunk(c, images, i0, n, features, ldfeat, s, sid, true));
+        const hipError_t ec = encoder_chunk(c, images, i0, n, features, ldfeat, s, sid, true);
+        if (ec != hipSuccess) {
+            c->co_running = 1;
+            return ec;
+        }
     }
+    c->co_running = 1;
     for (int k = 1; k < nstream; ++k) {
         HIPE(hipEventRecord(c->ev_join[k - 1], c->aux[k - 1]));
         HIPE(hipStreamWaitEvent(st, c->ev_join[k - 1], 0));
