@@ -25,6 +25,7 @@ class HpeError(RuntimeError):
 
 class HpeConfig(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_int),  # sizeof(HpeConfig); hpe_config_init writes it, hpe_create checks it
         ("device", C.c_int),
         ("max_batch", C.c_int),
         ("num_stage", C.c_int),
@@ -43,10 +44,11 @@ class HpeConfig(C.Structure):
         ("wino4_fused", C.c_int),
         ("bf16_p8", C.c_int),
         ("wino4_ksplit", C.c_int),
+        ("chain_fuse", C.c_int),
     ]
 
 
-PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4", "wino4_fused", "bf16_p8", "wino4_ksplit")
+PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4", "wino4_fused", "bf16_p8", "wino4_ksplit", "chain_fuse")
 
 
 class HpeSmplModel(C.Structure):
@@ -103,6 +105,7 @@ _PROTOS = {
                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_device_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpe_debug_conv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hpe_debug_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "hpe_debug_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_debug_gemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hpe_debug_set_dbg": (C.c_int, [C.c_void_p, C.c_void_p]),

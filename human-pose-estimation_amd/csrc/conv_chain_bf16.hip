@@ -1,0 +1,328 @@
+// conv_chain_bf16.hip -- back-to-back 1x1 fusion inside the ResNet bottleneck chain (bf16 encoder, BASELINE config 4):
+//
+//     t3 = relu(bn2c(W2c . t2) + x)          last 1x1 ("expand", C -> 4C) of identity block i      (Keras res*_branch2c + add + ReLU)
+//     u1 = relu(bn2a'(W2a' . t3))            first 1x1 ("reduce", 4C -> C') of identity block i+1   (Keras res*_branch2a + ReLU)
+//
+// as ONE launch (reference semantics: keras.applications.ResNet50 identity_block, src/models.py:35-41).
+// The two layers as separate launches move (C + 4C + 4C) + (4C + C') bf16 per pixel; here t3 is written once (it is the next
+// block's residual) and never read back: (C + 4C + 4C + C') -- 10 C instead of 14 C per pixel, -29 % of the bytes of the pair,
+// and the encoder is HBM-bound in bf16 (stage 2: the two launches run at 4.5-5.5 TB/s today).
+//
+// Rounding points are those of the two-launch path: t3 is rounded to bf16 where it is stored, and the second GEMM multiplies exactly
+// those bf16 values; only the fp32 summation order inside a k-slab differs.
+//
+// Structure (one workgroup = 64 pixels x all 4C channels, 4 waves, two workgroups per CU):
+//   * the workgroup walks the 4C axis in chunks of 128 channels.  Per chunk: GEMM-A (64 x 128, K = C) from the resident t2 tile,
+//     epilogue IN PLACE on the residual chunk that LDS-DMA has put in the A-operand slab layout (so the result is at once the bytes
+//     to store and the A operand of the next GEMM), 16-B row stores of t3, GEMM-B partial sums (64 x C', K = 128 of this chunk) in
+//     registers across the chunks.  The 4C-wide tensor never exists whole on the chip.
+//   * accumulators are kept TRANSPOSED (the weight fragment is the MFMA's A operand): a lane owns one pixel and 4 consecutive
+//     channels per register quad, so the in-place epilogue is one 8-byte LDS read + one 8-byte LDS write per quad.
+//   * the DMA issue is split by wave, because vmcnt is per wave and counts in issue order: waves 0-1 stream the weight slabs
+//     (L2 hits, waited at every slab), waves 2-3 move activations (t2 tile, residual chunk one chunk ahead, t3 stores: HBM latency)
+//     and wait only at the last GEMM-A barrier of a chunk, for a DMA that was issued a whole chunk earlier.
+//   * every wait in front of a barrier that publishes LDS-DMA data is written out (s_waitcnt vmcnt(0)): hipcc's __syncthreads()
+//     only waits for lgkmcnt.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hpe_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// per-channel scale / shift are read through the CONSTANT address space: the address is wave-uniform, so the loads become s_load (the
+// kernel also stores to global memory, which makes hipcc fall back to per-lane global_load for plain pointers -- those would queue
+// behind the LDS-DMA in flight, vmcnt counts in issue order)
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f32x4* cf32x4_p;
+
+#include "bf16_rows.h"
+
+namespace {
+
+__device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Barriers are written out: __syncthreads() is a workgroup fence + s_barrier, and behind pending LDS-DMA hipcc puts a vmcnt(0) in
+// front of some of them (here: the one after the in-place epilogue, which would make waves 2-3 wait for the residual chunk they have
+// only just requested) and only lgkmcnt(0) in front of others.  lds_barrier: LDS traffic of this wave is done, DMAs stay in flight;
+// the caller adds wait_dma() where the barrier publishes this wave's LDS-DMA data.
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// C  = channels of t2 (K of the expand GEMM), C4 = 4C = channels of t3, CP = output channels of the reduce GEMM
+template <int C, int CP>
+__global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
+    constexpr int BM = 64, NC = 128, C4 = 4 * C;
+    constexpr int KSA = C / 64, KSB = NC / 64, NCH = C4 / NC;
+    constexpr int SLAB = BM * 128;  // bytes of one [64 rows x 64 bf16] slab
+    constexpr int AT_OFF = 0, Q_OFF = KSA * SLAB, QBYTES = KSB * SLAB, WS_OFF = Q_OFF + 2 * QBYTES, WSB = 128 * 128;
+    constexpr int LDS_BYTES = WS_OFF + 2 * WSB;
+    constexpr int NTB = CP / 64;  // 32-wide n blocks of GEMM-B per wave (the wave owns CP / 2 channels)
+    static_assert(C % 64 == 0 && C4 % NC == 0 && (CP == 64 || CP == 128), "geometry");
+    static_assert(CP * 128 <= WSB && KSA * SLAB >= (CP / 64) * SLAB, "staging sizes");
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hi = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const bool w_loader = wave < 2;  // waves 0-1: weight slabs; waves 2-3: activations
+    const int lw = wave & 1;
+
+    // ---- DMA sources.  One wave-instruction fills 8 rows x 128 B; lane l -> row l >> 3, 16-B position l & 7 holds logical chunk
+    //      (l & 7) ^ ((row >> 1) & 7) (the swizzle the fragment reads undo).  A loader wave takes instructions ii = lw, lw + 2, ...
+    //      of a slab (rows 8 ii .. 8 ii + 7): the swizzle term does not depend on ii, so every address is a wave-uniform base
+    //      (SGPR pair) + ONE 32-bit per-lane byte offset per tensor -- 64-bit per-lane addresses for every unrolled DMA cost 255 VGPRs.
+    const int drow = lane >> 3;
+    const int r0 = 8 * lw + drow;                                // row of instruction ii = lw
+    const unsigned swz2 = (((lane & 7) ^ ((r0 >> 1) & 7)) * 8) * 2;  // bytes
+    unsigned off_t2[4], off_res[4];                              // activations: rows clamped to M - 1 on the last tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + r0 + 16 * i;
+        if (m >= p.M) m = p.M - 1;
+        off_t2[i] = (unsigned)m * (C * 2) + swz2;
+        off_res[i] = (unsigned)m * (C4 * 2) + swz2;
+    }
+    const unsigned off_wa = (unsigned)r0 * (unsigned)(p.ldw2c * 2) + swz2;
+    const unsigned off_wb = (unsigned)r0 * (unsigned)(p.ldw2a * 2) + swz2;
+    const char* T2b = reinterpret_cast<const char*>(p.t2);
+    const char* RESb = reinterpret_cast<const char*>(p.res);
+    const char* WAb = reinterpret_cast<const char*>(p.w2c);
+    const char* WBb = reinterpret_cast<const char*>(p.w2a);
+
+    auto issue_at = [&]() {  // t2 tile -> AT: KSA slabs
+#pragma unroll
+        for (int s = 0; s < KSA; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16(T2b + s * 128 + off_t2[i], lds + AT_OFF + s * SLAB + (lw + 2 * i) * 1024);
+    };
+    auto issue_res = [&](int c, int qb) {  // residual chunk c -> Q[qb]: KSB slabs
+#pragma unroll
+        for (int s = 0; s < KSB; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + qb * QBYTES + s * SLAB + (lw + 2 * i) * 1024);
+    };
+    auto issue_wa = [&](int c, int sa, int buf) {  // W2c rows [c * NC, +128), k-slab sa
+        const char* base = WAb + ((size_t)(c * NC) * p.ldw2c + sa * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16(base + (size_t)(16 * i) * p.ldw2c * 2 + off_wa, lds + WS_OFF + buf * WSB + (lw + 2 * i) * 1024);
+    };
+    auto issue_wb = [&](int c, int sb, int buf) {  // W2a' rows [0, CP), k-slab (c * NC + sb * 64)
+        const char* base = WBb + (c * NC + sb * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < CP / 16; ++i) dma16(base + (size_t)(16 * i) * p.ldw2a * 2 + off_wb, lds + WS_OFF + buf * WSB + (lw + 2 * i) * 1024);
+    };
+
+    // ---- fragment addressing (byte offsets inside a slab)
+    const int wm = wave >> 1;  // pixel half (32 rows) in both GEMMs
+    const int wn = wave & 1;   // channel half
+    const int ar = wm * 32 + (lane & 31);
+    const int a_off = ar * 128, a_x = (ar >> 1) & 7;
+    int wa_off[2], wa_x[2], wb_off[NTB], wb_x[NTB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wn * 64 + j * 32 + (lane & 31);
+        wa_off[j] = r * 128;
+        wa_x[j] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        const int r = wn * (CP / 2) + j * 32 + (lane & 31);
+        wb_off[j] = r * 128;
+        wb_x[j] = (r >> 1) & 7;
+    }
+
+    f32x16 accB[NTB];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accB[j][e] = 0.f;
+
+    // ---- prologue
+    if (w_loader) {
+        issue_wa(0, 0, 0);
+    } else {
+        issue_at();
+        issue_res(0, 0);
+    }
+
+    int w = 0;  // weight-slab counter (compile-time after unrolling): buffer = w & 1
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int qb = c & 1;
+        f32x16 accA[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accA[j][e] = 0.f;
+
+        // ================= GEMM-A: accA[n][m] = W2c[chunk c] . t2 tile
+#pragma unroll
+        for (int sa = 0; sa < KSA; ++sa) {
+            const int buf = w & 1;
+            // waves 0-1: their weight slab has landed.  Waves 2-3: at the first barrier (t2 tile) and at the LAST GEMM-A barrier of
+            // a chunk (its residual, issued one chunk ago) -- never behind a DMA they have only just issued.
+            if (w_loader || (c == 0 && sa == 0) || sa == KSA - 1) wait_dma();
+            lds_barrier();
+            if (w_loader) {
+                if (sa + 1 < KSA) issue_wa(c, sa + 1, buf ^ 1);
+                else issue_wb(c, 0, buf ^ 1);
+            } else if (sa == KSA - 1 && c + 1 < NCH) {
+                issue_res(c + 1, qb ^ 1);  // its buffer was last read in chunk c - 1
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 2 * g + hi;
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(lds + AT_OFF + sa * SLAB + a_off + ((lc ^ a_x) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 fw = *reinterpret_cast<const bf16x8*>(lds + WS_OFF + buf * WSB + wa_off[j] + ((lc ^ wa_x[j]) << 4));
+                    accA[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fa, accA[j], 0, 0, 0);
+                }
+            }
+            ++w;
+        }
+
+        // ================= epilogue-A, in place on Q[qb]: q = bf16(relu(acc * scale + shift + q))
+        // lane: pixel row ar, channels nb + 8 g + 4 hi + (0..3) of block j  ->  8 bytes of the slab row
+        {
+            unsigned char* Q = lds + Q_OFF + qb * QBYTES;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl0 = wn * 64 + j * 32;  // first channel of the block inside the chunk (wave-uniform)
+                cfloat_p scp = (cfloat_p)(p.scaleA + c * NC + nl0);
+                cfloat_p shp = (cfloat_p)(p.shiftA + c * NC + nl0);
+                unsigned char* Qs = Q + (nl0 >> 6) * SLAB + a_off;
+                const int kc0 = (nl0 & 63) >> 3;  // 16-B chunk of channel nl0 inside the 64-channel slab row
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned char* q = Qs + (((kc0 + g) ^ a_x) << 4) + hi * 8;
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(q);
+                    bf16x4 o;
+                    // two s_load_dwordx4 per vector (channels 8 g .. + 3 for lanes 0-31, 8 g + 4 .. + 7 for lanes 32-63), selected per element
+                    const f32x4 sc_lo = *reinterpret_cast<cf32x4_p>(scp + 8 * g), sc_hi = *reinterpret_cast<cf32x4_p>(scp + 8 * g + 4);
+                    const f32x4 sh_lo = *reinterpret_cast<cf32x4_p>(shp + 8 * g), sh_hi = *reinterpret_cast<cf32x4_p>(shp + 8 * g + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sc = hi ? sc_hi[k] : sc_lo[k];
+                        const float sh = hi ? sh_hi[k] : sh_lo[k];
+                        o[k] = (__bf16)fmaxf(accA[j][4 * g + k] * sc + sh + (float)rv[k], 0.f);
+                    }
+                    *reinterpret_cast<bf16x4*>(q) = o;
+                }
+            }
+        }
+        lds_barrier();  // Q[qb] is now the t3 tile of this chunk (LDS writes only; the DMAs in flight are not waited for)
+
+        // ================= t3 row stores (waves 2-3: they never wait on a fresh DMA) + GEMM-B partial sums
+        if (!w_loader) {
+            const unsigned char* Q = lds + Q_OFF + qb * QBYTES;
+            const int tt = t - 128;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int idx = pass * 128 + tt;  // 1024 units of 16 B: row = idx / 16, unit u = idx % 16
+                const int r = idx >> 4, u = idx & 15;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Q + (u >> 3) * SLAB + r * 128 + (((u & 7) ^ ((r >> 1) & 7)) << 4));
+                const int m = m0 + r;
+                if (m < p.M) *reinterpret_cast<bf16x8*>(p.t3 + (size_t)m * C4 + c * NC + u * 8) = v;
+            }
+        }
+#pragma unroll
+        for (int sb = 0; sb < KSB; ++sb) {
+            const int buf = w & 1;
+            if (w_loader) wait_dma();
+            lds_barrier();
+            if (w_loader) {
+                if (sb + 1 < KSB) issue_wb(c, sb + 1, buf ^ 1);
+                else if (c + 1 < NCH) issue_wa(c + 1, 0, buf ^ 1);
+            }
+            const unsigned char* Q = lds + Q_OFF + qb * QBYTES + sb * SLAB;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int lc = 2 * g + hi;
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(Q + a_off + ((lc ^ a_x) << 4));
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) {
+                    const bf16x8 fw = *reinterpret_cast<const bf16x8*>(lds + WS_OFF + buf * WSB + wb_off[j] + ((lc ^ wb_x[j]) << 4));
+                    accB[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fa, accB[j], 0, 0, 0);
+                }
+            }
+            ++w;
+        }
+    }
+
+    // ================= epilogue-B: u1 = bf16(relu(accB * scale' + shift')) -> LDS (the t2 tile's space, slab layout) -> 16-B row stores
+    lds_barrier();  // every wave is out of the last GEMM-B slab (and GEMM-A finished a chunk ago): AT is free
+    {
+        unsigned char* U = lds + AT_OFF;
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+            const int nl0 = wn * (CP / 2) + j * 32;
+            cfloat_p scp = (cfloat_p)(p.scaleB + nl0);
+            cfloat_p shp = (cfloat_p)(p.shiftB + nl0);
+            unsigned char* Us = U + (nl0 >> 6) * SLAB + a_off;
+            const int kc0 = (nl0 & 63) >> 3;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 o;
+                const f32x4 sc_lo = *reinterpret_cast<cf32x4_p>(scp + 8 * g), sc_hi = *reinterpret_cast<cf32x4_p>(scp + 8 * g + 4);
+                const f32x4 sh_lo = *reinterpret_cast<cf32x4_p>(shp + 8 * g), sh_hi = *reinterpret_cast<cf32x4_p>(shp + 8 * g + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sc = hi ? sc_hi[k] : sc_lo[k];
+                    const float sh = hi ? sh_hi[k] : sh_lo[k];
+                    o[k] = (__bf16)fmaxf(accB[j][4 * g + k] * sc + sh, 0.f);
+                }
+                *reinterpret_cast<bf16x4*>(Us + (((kc0 + g) ^ a_x) << 4) + hi * 8) = o;
+            }
+        }
+    }
+    lds_barrier();
+    {
+        constexpr int UPR = CP / 8;  // 16-B units per row
+        const unsigned char* U = lds + AT_OFF;
+#pragma unroll
+        for (int pass = 0; pass < (BM * UPR) / 256; ++pass) {
+            const int idx = pass * 256 + t;
+            const int r = idx / UPR, u = idx - r * UPR;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(U + (u >> 3) * SLAB + r * 128 + (((u & 7) ^ ((r >> 1) & 7)) << 4));
+            const int m = m0 + r;
+            if (m < p.M) *reinterpret_cast<bf16x8*>(p.u1 + (size_t)m * CP + u * 8) = v;
+        }
+    }
+}
+
+template <int C, int CP>
+hipError_t launch_chain(const ChainArgs& p, hipStream_t st) {
+    const int grid = (p.M + 63) / 64;
+    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP>), dim3(grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool hpe_chain_bf16_supported(int C, int C4, int CP) { return C4 == 4 * C && CP == C && (C == 64 || C == 128); }
+
+hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, hipStream_t st) {
+    if (!hpe_chain_bf16_supported(C, C4, CP)) return hipErrorInvalidValue;
+    if (p.M <= 0 || !p.t2 || !p.res || !p.w2c || !p.w2a || !p.t3 || !p.u1 || !p.scaleA || !p.shiftA || !p.scaleB || !p.shiftB) return hipErrorInvalidValue;
+    if (p.ldw2c < C || p.ldw2a < C4 || (p.ldw2c % 8) != 0 || (p.ldw2a % 8) != 0) return hipErrorInvalidValue;
+    if ((((uintptr_t)p.t2 | (uintptr_t)p.res | (uintptr_t)p.w2c | (uintptr_t)p.w2a | (uintptr_t)p.t3 | (uintptr_t)p.u1) & 15) != 0) return hipErrorInvalidValue;
+    if (C == 64) return launch_chain<64, 64>(p, st);
+    return launch_chain<128, 128>(p, st);
+}
+
+// resident workgroups per CU of the two instantiations (the design needs 2): out[0] C = 64, out[1] C = 128
+hipError_t hpe_chain_bf16_occupancy(int out[2]) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<64, 64>), 256, 0);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<128, 128>), 256, 0);
+}

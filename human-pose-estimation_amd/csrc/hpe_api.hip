@@ -200,6 +200,8 @@ struct hpe_ctx {
     unsigned pipe_idx = 0;
     float* feat_alt = nullptr;
     int wino4_ksplit = 1;  // plan option wino4_ksplit / HPE_WINO4_KSPLIT
+    int chain_fuse = 0;    // bf16 only: stages (bit 0: stage 2, bit 1: stage 3) whose identity blocks run branch2c + the next block's branch2a as
+                           // one launch (conv_chain_bf16.hip); plan option chain_fuse / HPE_CHAIN
     int co_running = 1;    // chunk streams of the encoder call being enqueued (launch-size rules of the F(4x4) kernels)
     float* w4_split = nullptr;  // F(4x4) C-axis split workspaces + counters (4 x hpe_wino4_split_ws_floats: one per chunk-stream slot)
     float* partial_tail = nullptr;
@@ -457,6 +459,36 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
     return hpe_launch_gemm(p, GEMM_DUAL, pick_tile(c->knobs, p.M, p.N, p.K, false, (flags & CONV_CONCURRENT) != 0), st);
 }
 
+// the bf16 identity-block pair branch2c (idx i2c, + residual + ReLU) -> next block's branch2a (idx i2c + 1) as one launch
+bool use_chain(const hpe_ctx* c, int stg, int i2c, bool first, bool has_next) {
+    if (!c->bf16 || first || !has_next || !((c->chain_fuse >> stg) & 1)) return false;
+    const ConvSpec& s2 = specs()[i2c];
+    const ConvSpec& sn = specs()[i2c + 1];
+    return sn.kh == 1 && sn.stride == 1 && sn.cin == s2.cout && hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout);
+}
+
+hipError_t run_chain(hpe_ctx* c, int i2c, const float* t2, const float* res, int B, float* t3, float* u1, hipStream_t st) {
+    const ConvSpec& s2 = specs()[i2c];
+    const ConvSpec& sn = specs()[i2c + 1];
+    const ConvLayer& L2 = c->conv[i2c];
+    const ConvLayer& Ln = c->conv[i2c + 1];
+    ChainArgs p{};
+    p.t2 = reinterpret_cast<const __bf16*>(t2);
+    p.res = reinterpret_cast<const __bf16*>(res);
+    p.w2c = reinterpret_cast<const __bf16*>(L2.w);
+    p.w2a = reinterpret_cast<const __bf16*>(Ln.w);
+    p.scaleA = L2.scale;
+    p.shiftA = L2.shift;
+    p.scaleB = Ln.scale;
+    p.shiftB = Ln.shift;
+    p.t3 = reinterpret_cast<__bf16*>(t3);
+    p.u1 = reinterpret_cast<__bf16*>(u1);
+    p.M = B * s2.hout * s2.hout;
+    p.ldw2c = L2.k_pad;
+    p.ldw2a = Ln.k_pad;
+    return hpe_launch_chain_bf16(p, s2.cin, s2.cout, sn.cout, st);
+}
+
 hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
                      const float* shift, const float* res, int ldres, int relu, float* y, int ldy, hipStream_t st) {
     // single frames and very small batches: one launch per layer (the implicit-GEMM kernel would need split-K + a fix-up launch)
@@ -533,15 +565,32 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
     }
     int ci = 1;
     const int nblk[4] = {3, 4, 6, 3};
+    bool have_2a = false;  // the previous block's chained launch has already written this block's branch2a output to T1
     for (int stg = 0; stg < 4; ++stg) {
         for (int b = 0; b < nblk[stg]; ++b) {
             const bool first = b == 0;
             const int i2a = ci, i2b = ci + 1, i2c = ci + 2, i1 = ci + 3;
             const bool fz = use_wino_fused(c, i2b, B) || use_wino4_fused(c, i2b, B);  // then T1 is channel-slab major and never leaves this pair of launches
-            HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, cf | (fz ? CONV_OUT_SLAB8 : 0)));
+            if (have_2a) {
+                if (c->timing >= 2) {
+                    HIPE(hipEventRecord(c->cev0[i2a], st));
+                    HIPE(hipEventRecord(c->cev1[i2a], st));
+                }
+            } else {
+                HIPE(timed_conv(c, i2a, cur, B, nullptr, 1, T1, st, nullptr, 0, cf | (fz ? CONV_OUT_SLAB8 : 0)));
+            }
+            have_2a = false;
             HIPE(timed_conv(c, i2b, T1, B, nullptr, 1, T2, st, wv, slot, cf | (fz ? CONV_IN_SLAB8 : 0)));
             const float* res = cur;
-            if (first && c->conv[i2c].w_dual) {
+            if (use_chain(c, stg, i2c, first, b + 1 < nblk[stg])) {
+                // identity block followed by an identity block (bf16): relu(bn(W2c t2) + x) and the next block's relu(bn(W2a' .)) in one
+                // launch; the 4C-wide sum is written once and not read back (timed as layer i2c; the next branch2a then shows 0)
+                const bool t2 = c->timing >= 2;
+                if (t2) HIPE(hipEventRecord(c->cev0[i2c], st));
+                HIPE(run_chain(c, i2c, T2, cur, B, nxt, T1, st));
+                if (t2) HIPE(hipEventRecord(c->cev1[i2c], st));
+                have_2a = true;
+            } else if (first && c->conv[i2c].w_dual) {
                 // conv_block: expand convolution + projection shortcut + add + ReLU as one dual-source GEMM (timed as layer i2c)
                 const bool t2 = c->timing >= 2;
                 if (t2) HIPE(hipEventRecord(c->cev0[i2c], st));
@@ -667,17 +716,23 @@ int hpe_conv_layer_geometry(int idx, int out[7]) {
 
 void hpe_config_init(HpeConfig* cfg) {
     if (!cfg) return;
+    cfg->struct_size = (int)sizeof(HpeConfig);
     cfg->device = 0;
     cfg->max_batch = 8;
     cfg->num_stage = 3;
     cfg->bn_eps = 1e-3f;
     cfg->encoder_dtype = 0;
     cfg->n_streams = cfg->dual_gemm = cfg->stem_fused = cfg->wino_min_c = cfg->wino_min_items = cfg->wino_fused = -1;
-    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = cfg->wino4_ksplit = -1;
+    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = cfg->wino4_ksplit = cfg->chain_fuse = -1;
 }
 
 int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
     if (!cfg || !out) return fail(HPE_ERR_INVALID, "null argument");
+    // The struct has grown every round: a caller built against another header (or one that zero-initialised the struct instead of
+    // calling hpe_config_init) is refused here instead of having plan options read from past the end of its struct.
+    if (cfg->struct_size != (int)sizeof(HpeConfig))
+        return fail(HPE_ERR_INVALID, "HpeConfig.struct_size is " + std::to_string(cfg->struct_size) + ", this library expects " +
+                                         std::to_string(sizeof(HpeConfig)) + ": fill the struct with hpe_config_init() of the same header");
     if (cfg->n_streams > 4 || cfg->n_streams == 0) return fail(HPE_ERR_INVALID, "n_streams must be -1 (default) or 1..4");
     if (cfg->mesh_a2b > 2) return fail(HPE_ERR_INVALID, "mesh_a2b must be -1 (default), 0 (grid), 1 (valu) or 2 (mfma)");
     if (cfg->max_batch < 1 || cfg->max_batch > 1024) return fail(HPE_ERR_INVALID, "max_batch must be in [1,1024]");
@@ -856,6 +911,7 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
         c->wino4_ksplit = opt(c->cfg.wino4_ksplit, "HPE_WINO4_KSPLIT", 1);
+        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 3) & 3) : 0;
         c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
@@ -1608,6 +1664,27 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
         return HPE_OK;
     }
     HIP_TRY(run_conv(c, idx, in, B, residual, relu, y, st, c->wino_v));
+    return HPE_OK;
+}
+
+int hpe_debug_chain(hpe_ctx* c, int idx2c, const float* t2, const float* residual, int B, float* t3, float* u1, int* occupancy, void* stream) {
+    int rc = check_ready(c, B, NEED_ENC);
+    if (rc) return rc;
+    if (!c->bf16) return fail(HPE_ERR_STATE, "hpe_debug_chain works on bf16 contexts only");
+    if (idx2c < 1 || idx2c + 1 >= HPE_NUM_CONV || !t2 || !residual || !t3 || !u1) return fail(HPE_ERR_INVALID, "bad argument");
+    const ConvSpec& s2 = specs()[idx2c];
+    const ConvSpec& sn = specs()[idx2c + 1];
+    if (s2.kh != 1 || s2.cout != 4 * s2.cin || sn.kh != 1 || sn.stride != 1 || sn.cin != s2.cout || !hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout))
+        return fail(HPE_ERR_INVALID, "hpe_debug_chain: idx2c must be the branch2c of a stage-2 / stage-3 block that is followed by an identity block");
+    DeviceGuard g(c->cfg.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long M = (long)B * s2.hout * s2.hout;
+    HIP_TRY(hpe_launch_f32_to_bf16(t2, c->T2, M * s2.cin, st));
+    HIP_TRY(hpe_launch_f32_to_bf16(residual, c->X0, M * s2.cout, st));
+    HIP_TRY(run_chain(c, idx2c, c->T2, c->X0, B, c->X1, c->T1, st));
+    HIP_TRY(hpe_launch_bf16_to_f32(c->X1, t3, M * s2.cout, st));
+    HIP_TRY(hpe_launch_bf16_to_f32(c->T1, u1, M * sn.cout, st));
+    if (occupancy) HIP_TRY(hpe_chain_bf16_occupancy(occupancy));
     return HPE_OK;
 }
 

@@ -80,6 +80,22 @@ int hpe_wino4_fused_items(int B, int H, int W, int N);  // workgroups of that la
 hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ring_depth, hipStream_t st);  // ring_depth 2..4 LDS slab buffers
 // conv_gemm_bf16_p8.hip: 256 x 256 x 64 tile, 8 waves, phase-interleaved main loop, split-K through p.partial (DENSE / STRIDED / CONV3 / DUAL)
 hipError_t hpe_launch_gemm_bf16_p8(GemmArgs p, int mode, hipStream_t st);
+// conv_chain_bf16.hip: t3 = relu(bn(W2c . t2) + res) and u1 = relu(bn'(W2a' . t3)) in one launch (the last 1x1 of identity block i and the
+// first 1x1 of identity block i + 1); all tensors bf16, row-major [M, channels], weights packed [n][k]
+struct ChainArgs {
+    const __bf16* t2;   // [M, C]
+    const __bf16* res;  // [M, 4C]
+    const __bf16* w2c;  // [4C][ldw2c]
+    const __bf16* w2a;  // [C'][ldw2a]
+    const float *scaleA, *shiftA;  // [4C]
+    const float *scaleB, *shiftB;  // [C']
+    __bf16* t3;  // [M, 4C]
+    __bf16* u1;  // [M, C']
+    int M, ldw2c, ldw2a;
+};
+bool hpe_chain_bf16_supported(int C, int C4, int CP);
+hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, hipStream_t st);
+hipError_t hpe_chain_bf16_occupancy(int out[2]);
 hipError_t hpe_launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);  // round to nearest even
 hipError_t hpe_launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t st);
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);

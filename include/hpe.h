@@ -52,6 +52,8 @@ extern "C" {
 typedef struct hpe_ctx hpe_ctx;
 
 typedef struct HpeConfig {
+    int struct_size; /* sizeof(HpeConfig) of the header the caller was built with; written by hpe_config_init, checked by hpe_create
+                      * (HPE_ERR_INVALID on a mismatch: the struct has grown every round, a short or zero-initialised one is refused) */
     int device;     /* HIP device ordinal */
     int max_batch;  /* workspace is sized for this many images per call (<= 1024) */
     int num_stage;  /* IEF iterations; reference default 3 (src/config.py:39) */
@@ -78,9 +80,13 @@ typedef struct HpeConfig {
                             *                      launch of res5a, 16 the other dual-source launches */
     int wino4_ksplit;      /* HPE_WINO4_KSPLIT     small F(4x4) launches cut their channel axis into 2-4 parts that are added in part order
                             *                      (1); 0 = never (one summation order per output whatever the batch) */
+    int chain_fuse;        /* HPE_CHAIN            bf16 encoder: stages (1 = stage 2, 2 = stage 3) whose identity blocks run res*_branch2c + add +
+                            *                      ReLU and the NEXT block's res*_branch2a + ReLU as one launch: the 4C-wide block output is
+                            *                      written once and not read back (3); same bf16 rounding points as the two launches */
 } HpeConfig;
 
-/* defaults: device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1 */
+/* defaults: struct_size = sizeof(HpeConfig), device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1.
+ * ALWAYS start from this call: hpe_create refuses a struct whose struct_size is not the library's. */
 void hpe_config_init(HpeConfig* cfg);
 
 /* SMPL constants as the reference holds them after SMPL.__init__ (src/tf_smpl/batch_smpl.py:31-81),
@@ -222,6 +228,12 @@ int hpe_get_original(const float* verts_dev, const float* cam_dev, int B, int P,
  * layer runs through the bf16 kernel the plan picks for this batch, and y is its bf16 output widened to float. */
 int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float* residual_dev, int relu, float* y_dev,
                    void* stream);
+/* bf16 contexts: the chained launch of conv_chain_bf16.hip alone.  idx2c = res{2,3}{b..}_branch2c of a block that is followed by an
+ * identity block: t2_dev [B,H,H,C], residual_dev [B,H,H,4C] (rounded to bf16 on the way in) -> t3_dev [B,H,H,4C] =
+ * relu(bn(conv2c(t2)) + residual) and u1_dev [B,H,H,C] = relu(bn(conv2a_next(t3))), both widened to float.  occupancy (host, optional,
+ * 2 ints): resident workgroups per CU of the two instantiations (the design needs 2). */
+int hpe_debug_chain(hpe_ctx* ctx, int idx2c, const float* t2_dev, const float* residual_dev, int B, float* t3_dev, float* u1_dev,
+                    int* occupancy, void* stream);
 /* The fused stem kernel alone (conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + MaxPooling2D(3,2) of the Keras ResNet50,
  * src/models.py:39): images_dev [B,224,224,3] -> y_dev [B,56,56,64].  rows_per_strip: pooled rows per workgroup
  * (1, 2, 4, 7 or 8; 0 = the default for this batch).  fp32 contexts only. */

@@ -41,11 +41,42 @@ def test_config_struct_matches_header(lib):
     fields = re.findall(r"\b(?:int|float)\s+([a-z_0-9]+)\s*;", body)
     assert fields == [f[0] for f in _lib.HpeConfig._fields_]
     assert C.sizeof(_lib.HpeConfig) == 4 * len(fields)
-    assert tuple(fields[5:]) == _lib.PLAN_OPTIONS
+    assert fields[0] == "struct_size" and tuple(fields[6:]) == _lib.PLAN_OPTIONS
     cfg = _lib.HpeConfig()
     lib.hpe_config_init(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(_lib.HpeConfig)
     assert (cfg.device, cfg.max_batch, cfg.num_stage, cfg.encoder_dtype) == (0, 8, 3, 0) and abs(cfg.bn_eps - 1e-3) < 1e-9
     assert all(getattr(cfg, k) == -1 for k in _lib.PLAN_OPTIONS)
+
+
+def test_create_refuses_foreign_config_struct(lib):
+    """hpe_create checks HpeConfig.struct_size before it reads anything else: a zero-initialised struct (hpe_config_init not called: every
+    plan option would read 0 = the slowest plan) and a struct of another header revision (shorter: the library would read plan options
+    from past its end) are refused with HPE_ERR_INVALID and a message naming both sizes.  Runs without a GPU: the check comes first."""
+    import ctypes as C
+
+    h = C.c_void_p()
+    zeroed = _lib.HpeConfig()  # ctypes zero-fills
+    assert lib.hpe_create(C.byref(zeroed), C.byref(h)) == 1 and not h.value
+    assert b"struct_size is 0" in lib.hpe_last_error()
+
+    class OldConfig(C.Structure):  # the round-3 layout: no struct_size, 17 scalars
+        _fields_ = [(n, t) for n, t in _lib.HpeConfig._fields_[1:-1]]
+
+    old = OldConfig(device=0, max_batch=8, num_stage=3, bn_eps=1e-3, encoder_dtype=0, n_streams=-1)
+    assert lib.hpe_create(C.cast(C.byref(old), C.POINTER(_lib.HpeConfig)), C.byref(h)) == 1 and not h.value
+    short = _lib.HpeConfig()
+    lib.hpe_config_init(C.byref(short))
+    short.struct_size -= 4  # one field fewer: a stub built against the previous header
+    assert lib.hpe_create(C.byref(short), C.byref(h)) == 1 and not h.value
+    msg = lib.hpe_last_error().decode()
+    assert str(C.sizeof(_lib.HpeConfig) - 4) in msg and str(C.sizeof(_lib.HpeConfig)) in msg, msg
+    good = _lib.HpeConfig()
+    lib.hpe_config_init(C.byref(good))
+    rc = lib.hpe_create(C.byref(good), C.byref(h))
+    assert rc in (0, 4), rc  # 4 = HPE_ERR_NO_DEVICE in the build container: the struct itself was accepted
+    if rc == 0:
+        lib.hpe_destroy(h)
 
 
 def test_layer_table_matches_host_spec(lib):

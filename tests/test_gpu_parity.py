@@ -1000,6 +1000,77 @@ def test_bf16_p8_encoder_matches_round2_encoder(engines_bf16_old_and_p8, assets)
     assert float(np.linalg.norm(fn - fo) / np.linalg.norm(fo)) < 3e-3
 
 
+# ------------------------------------------------------------------------------------------- bf16 chained 1x1 launches (round 4)
+@pytest.fixture(scope="module")
+def engines_bf16_chain_off_on(assets):
+    """Two bf16 encoder contexts: every layer its own launch (chain_fuse=0) and the identity blocks of stages 2-3 with branch2c + the next
+    block's branch2a as one launch (chain_fuse=3, the default)."""
+    made = [encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=0), encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=3)]
+    yield made
+    for e in made:
+        e.close()
+
+
+@pytest.mark.parametrize("name", ["res2b_branch2c", "res3b_branch2c", "res3c_branch2c"])
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_bf16_chain_matches_oracle_and_two_launches(engines_bf16_chain_off_on, assets, name, B):
+    """conv_chain_bf16.hip: t3 = relu(bn(W2c t2) + x), u1 = relu(bn'(W2a' t3)) in one launch against (i) the fp64 evaluation of the same
+    bf16-rounded operands with t3 rounded to bf16 where the kernel stores it, (ii) the two separate launches of the round-2 kernel --
+    same rounding points, so they differ by fp32 summation order only (at most one bf16 ulp).  M = 3136 B / 784 B: the last 64-row tile is
+    partial for odd B on the 28 x 28 maps (784 = 12.25 x 64)."""
+    off, on = engines_bf16_chain_off_on
+    idx = resnet_spec.CONV_INDEX[name]
+    s, sn = resnet_spec.CONV_SPECS[idx], resnet_spec.CONV_SPECS[idx + 1]
+    g = np.random.Generator(np.random.Philox(2100 + idx + B))
+    t2 = np.maximum(g.normal(0, 1, (B, s.hin, s.hin, s.cin)), 0).astype(np.float32)
+    x = np.maximum(g.normal(0, 2, (B, s.hin, s.hin, s.cout)), 0).astype(np.float32)
+    t2[0, 0, 0, :] = 20.0
+    t3, u1, occ = on.debug_chain(idx, gpu(t2), gpu(x))
+    t3, u1 = cpu(t3), cpu(u1)
+    print("chain kernel: resident workgroups per CU (C = 64, C = 128): %s" % (occ,))
+    assert occ[0] >= 2 and occ[1] >= 2, occ
+    # (ii) the two launches
+    t3_two = cpu(off.debug_conv(idx, gpu(t2), residual=gpu(x), relu=True))
+    u1_two = cpu(off.debug_conv(idx + 1, gpu(t3_two), relu=True))
+    ulp = 2.0 ** -8
+    assert rel(t3, t3_two) < ulp, rel(t3, t3_two)
+    assert rel(u1, u1_two) < 2 * ulp, rel(u1, u1_two)  # a one-ulp flip of t3 moves u1 too
+    assert float(np.linalg.norm(u1 - u1_two) / np.linalg.norm(u1_two)) < 1e-3
+    # (i) fp64 on the rounded operands
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    scn, shn = _bn_fold(p, sn)
+    lin = O.conv2d_nhwc(_bf16_round(t2), _bf16_round(p[s.name + "/kernel"]), p[s.name + "/bias"], 1, 0, dtype=np.float64) * sc + sh
+    ref3 = np.maximum(lin + _bf16_round(x).astype(np.float64), 0)
+    assert rel(t3, ref3) < ulp, rel(t3, ref3)
+    lin = O.conv2d_nhwc(_bf16_round(ref3), _bf16_round(p[sn.name + "/kernel"]), p[sn.name + "/bias"], 1, 0, dtype=np.float64) * scn + shn
+    ref1 = np.maximum(lin, 0)
+    assert rel(u1, ref1) < 2 * ulp, rel(u1, ref1)
+    assert float(np.linalg.norm(u1 - ref1) / np.linalg.norm(ref1)) < 2.5e-3
+
+
+def test_bf16_chain_encoder_matches_unchained(engines_bf16_chain_off_on, assets):
+    """Whole bf16 encoder with and without the chained launches: features within the bf16 tolerance of each other and of the
+    rounding-point-emulating oracle (the chained launch keeps the rounding points), one chunk and two concurrent chunks, and the metric
+    batch against itself (rows of B = 256 equal the same images in a batch of 3)."""
+    off, on = engines_bf16_chain_off_on
+    img = gpu(synthetic.make_images(5, seed=91))
+    fo, fn = cpu(off.encoder(img)).astype(np.float64), cpu(on.encoder(img)).astype(np.float64)
+    l2 = float(np.linalg.norm(fn - fo) / np.linalg.norm(fo))
+    print("bf16 chained encoder vs one launch per layer: rel-L2 %.3g" % l2)
+    assert l2 < 2e-3
+    ref = O.resnet50_features(cpu(img[:2]), assets["enc"], act_round="bf16", bf16_folded=BF16_FOLDED)
+    assert float(np.linalg.norm(fn[:2] - ref) / np.linalg.norm(ref)) < 3e-3
+    big = gpu(synthetic.make_images(256, seed=92))
+    fb = cpu(on.encoder(big)).astype(np.float64)
+    fo = cpu(off.encoder(big)).astype(np.float64)
+    assert float(np.linalg.norm(fb - fo) / np.linalg.norm(fo)) < 2e-3
+    pick = [0, 127, 128, 255]
+    fs = cpu(on.encoder(big[pick].contiguous())).astype(np.float64)
+    assert float(np.linalg.norm(fb[pick] - fs) / np.linalg.norm(fs)) < 1e-3
+    assert np.array_equal(fb, cpu(on.encoder(big)).astype(np.float64))  # bitwise repeatable
+
+
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
 @pytest.mark.parametrize("variant", ["survey", "bounded"])
 @pytest.mark.parametrize("B", [64, 256])
