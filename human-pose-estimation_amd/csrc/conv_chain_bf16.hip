@@ -12,17 +12,21 @@
 // those bf16 values; only the fp32 summation order inside a k-slab differs.
 //
 // Structure (one workgroup = 64 pixels x all 4C channels, 4 waves, two workgroups per CU):
-//   * the workgroup walks the 4C axis in chunks of 128 channels.  Per chunk: GEMM-A (64 x 128, K = C) from the resident t2 tile,
-//     epilogue IN PLACE on the residual chunk that LDS-DMA has put in the A-operand slab layout (so the result is at once the bytes
-//     to store and the A operand of the next GEMM), 16-B row stores of t3, GEMM-B partial sums (64 x C', K = 128 of this chunk) in
-//     registers across the chunks.  The 4C-wide tensor never exists whole on the chip.
+//   * the workgroup walks the 4C axis in chunks of NC channels (128 in stage 2, 64 in stage 3).  Per chunk: GEMM-A (64 x NC, K = C) from
+//     the resident t2 tile, epilogue IN PLACE on the residual chunk that LDS-DMA has put in the A-operand slab layout (so the result is
+//     at once the bytes to store and the A operand of the next GEMM), 16-B row stores of t3, GEMM-B partial sums (64 x C', K = NC of
+//     this chunk) in registers across the chunks.  The 4C-wide tensor never exists whole on the chip.  Two barriers per chunk.
 //   * accumulators are kept TRANSPOSED (the weight fragment is the MFMA's A operand): a lane owns one pixel and 4 consecutive
 //     channels per register quad, so the in-place epilogue is one 8-byte LDS read + one 8-byte LDS write per quad.
-//   * the DMA issue is split by wave, because vmcnt is per wave and counts in issue order: waves 0-1 stream the weight slabs
-//     (L2 hits, waited at every slab), waves 2-3 move activations (t2 tile, residual chunk one chunk ahead, t3 stores: HBM latency)
-//     and wait only at the last GEMM-A barrier of a chunk, for a DMA that was issued a whole chunk earlier.
-//   * every wait in front of a barrier that publishes LDS-DMA data is written out (s_waitcnt vmcnt(0)): hipcc's __syncthreads()
-//     only waits for lgkmcnt.
+//   * a workgroup computes for ~1 us per tile and HBM answers after ~3 us, so everything a tile needs is requested up front: the t2
+//     tile and a 32 KB ring of residual chunks (all of them in stage 2, four of eight in stage 3; refilled as chunks retire) -- two
+//     workgroups per CU keep ~100 KB in flight.  The weights of a chunk (16 KB for GEMM-A, 16 KB for GEMM-B, L2 hits) have one slot
+//     each and are requested as soon as the previous chunk has released the slot.
+//   * vmcnt is per wave and counts in issue order, so the roles are split by wave: wave 0 streams the weight slots (waited at every
+//     barrier that needs one), wave 1 writes the t3 rows (never waits), waves 2-3 issue the activation DMAs and wait with a COUNTED
+//     vmcnt for the oldest residual chunk only (their queue holds loads only, which retire in order).
+//   * every wait in front of a barrier that publishes LDS-DMA data is written out: hipcc's __syncthreads() only waits for lgkmcnt
+//     behind some DMA patterns and for vmcnt(0) behind others (rounds 3-4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,17 +57,36 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// C  = channels of t2 (K of the expand GEMM), C4 = 4C = channels of t3, CP = output channels of the reduce GEMM
-template <int C, int CP>
+// counted wait: all but the wave's n youngest vector-memory operations (LDS-DMA, loads and stores count together, in issue order) are
+// done.  n is a compile-time constant after unrolling; inline asm needs an immediate.
+__device__ __forceinline__ void wait_dma_leaving(int n, bool exact_counts) {
+    if (!exact_counts) n = 0;
+    switch (n) {
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // 0, and anything unforeseen: over-waiting is safe
+    }
+}
+
+// C = channels of t2 (K of the expand GEMM), 4C = channels of t3, CP = output channels of the reduce GEMM, NC = channels per chunk
+template <int C, int CP, int NC>
 __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
-    constexpr int BM = 64, NC = 128, C4 = 4 * C;
+    constexpr int BM = 64, C4 = 4 * C;
     constexpr int KSA = C / 64, KSB = NC / 64, NCH = C4 / NC;
     constexpr int SLAB = BM * 128;  // bytes of one [64 rows x 64 bf16] slab
-    constexpr int AT_OFF = 0, Q_OFF = KSA * SLAB, QBYTES = KSB * SLAB, WS_OFF = Q_OFF + 2 * QBYTES, WSB = 128 * 128;
-    constexpr int LDS_BYTES = WS_OFF + 2 * WSB;
-    constexpr int NTB = CP / 64;  // 32-wide n blocks of GEMM-B per wave (the wave owns CP / 2 channels)
-    static_assert(C % 64 == 0 && C4 % NC == 0 && (CP == 64 || CP == 128), "geometry");
-    static_assert(CP * 128 <= WSB && KSA * SLAB >= (CP / 64) * SLAB, "staging sizes");
+    constexpr int QBYTES = KSB * SLAB, QBUFS = 32768 / QBYTES;
+    constexpr int WA_SLAB = NC * 128, WB_SLAB = CP * 128;  // one k-slab of the GEMM-A / GEMM-B weights of a chunk
+    constexpr int AT_OFF = 0, Q_OFF = KSA * SLAB, WA_OFF = Q_OFF + QBUFS * QBYTES, WB_OFF = WA_OFF + KSA * WA_SLAB;
+    constexpr int LDS_BYTES = WB_OFF + KSB * WB_SLAB;
+    constexpr int NTA = NC / 64, NTB = CP / 64;  // 32-wide channel blocks per wave (a wave owns half the chunk / half of C')
+    // vector-memory instructions per wave of each group (every wave issues a quarter of every group)
+    constexpr int RI = KSB * 2, WI = 4, ST = NC / 32;  // residual chunk, one weight slot, t3 stores of a chunk
+    static_assert(C % 64 == 0 && C4 % NC == 0 && (NC == 64 || NC == 128) && (CP == 64 || CP == 128), "geometry");
+    static_assert(KSA * WA_SLAB == 16384 && KSB * WB_SLAB == 16384 && QBUFS * QBYTES == 32768 && QBUFS <= NCH, "slot sizes");
+    static_assert(KSA * SLAB >= (CP / 64) * SLAB, "the u1 tile reuses the t2 tile's space");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -73,26 +96,28 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = lane >> 5;
     const int m0 = blockIdx.x * BM;
-    const bool w_loader = wave < 2;  // waves 0-1: weight slabs; waves 2-3: activations
-    const int lw = wave & 1;
+    // The counted waits assume that every wave has issued every store instruction of the schedule.  On the last, partial tile a wave whose
+    // rows all lie beyond M skips its stores (exec == 0 branches over them): there every wait drains the queue instead.
+    const bool full_tile = m0 + BM <= p.M;
 
     // ---- DMA sources.  One wave-instruction fills 8 rows x 128 B; lane l -> row l >> 3, 16-B position l & 7 holds logical chunk
-    //      (l & 7) ^ ((row >> 1) & 7) (the swizzle the fragment reads undo).  A loader wave takes instructions ii = lw, lw + 2, ...
-    //      of a slab (rows 8 ii .. 8 ii + 7): the swizzle term does not depend on ii, so every address is a wave-uniform base
-    //      (SGPR pair) + ONE 32-bit per-lane byte offset per tensor -- 64-bit per-lane addresses for every unrolled DMA cost 255 VGPRs.
+    //      (l & 7) ^ ((row >> 1) & 7) (the swizzle the fragment reads undo).  Every address is a wave-uniform base (SGPR pair) + a
+    //      32-bit per-lane byte offset (64-bit per-lane addresses for every unrolled DMA cost 255 VGPRs).
     const int drow = lane >> 3;
-    const int r0 = 8 * lw + drow;                                // row of instruction ii = lw
-    const unsigned swz2 = (((lane & 7) ^ ((r0 >> 1) & 7)) * 8) * 2;  // bytes
-    unsigned off_t2[4], off_res[4];                              // activations: rows clamped to M - 1 on the last tile
+    // Every wave issues a quarter of every group: instructions ii = wave, wave + 4, ... (rows 8 ii .. + 7).  The swizzle term
+    // ((row >> 1) & 7) = (4 ii + (drow >> 1)) & 7 depends on the parity of ii only, i.e. on the wave.
+    const int r0 = 8 * wave + drow;
+    const unsigned swz_a = (((lane & 7) ^ ((r0 >> 1) & 7)) * 8) * 2;
+    unsigned off_t2[2], off_res[2];  // activation rows r0, r0 + 32, clamped to M - 1 on the last tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + r0 + 16 * i;
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + r0 + 32 * i;
         if (m >= p.M) m = p.M - 1;
-        off_t2[i] = (unsigned)m * (C * 2) + swz2;
-        off_res[i] = (unsigned)m * (C4 * 2) + swz2;
+        off_t2[i] = (unsigned)m * (C * 2) + swz_a;
+        off_res[i] = (unsigned)m * (C4 * 2) + swz_a;
     }
-    const unsigned off_wa = (unsigned)r0 * (unsigned)(p.ldw2c * 2) + swz2;
-    const unsigned off_wb = (unsigned)r0 * (unsigned)(p.ldw2a * 2) + swz2;
+    const unsigned off_wa = (unsigned)r0 * (unsigned)(p.ldw2c * 2) + swz_a;  // weight rows r0 + 32 i: the row step is wave-uniform
+    const unsigned off_wb = (unsigned)r0 * (unsigned)(p.ldw2a * 2) + swz_a;
     const char* T2b = reinterpret_cast<const char*>(p.t2);
     const char* RESb = reinterpret_cast<const char*>(p.res);
     const char* WAb = reinterpret_cast<const char*>(p.w2c);
@@ -102,23 +127,32 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
 #pragma unroll
         for (int s = 0; s < KSA; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dma16(T2b + s * 128 + off_t2[i], lds + AT_OFF + s * SLAB + (lw + 2 * i) * 1024);
+            for (int i = 0; i < 2; ++i) dma16(T2b + s * 128 + off_t2[i], lds + AT_OFF + s * SLAB + (wave + 4 * i) * 1024);
     };
-    auto issue_res = [&](int c, int qb) {  // residual chunk c -> Q[qb]: KSB slabs
+    auto issue_res = [&](int c) {  // residual chunk c -> Q[c % QBUFS]: KSB slabs
 #pragma unroll
         for (int s = 0; s < KSB; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dma16(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + qb * QBYTES + s * SLAB + (lw + 2 * i) * 1024);
+            for (int i = 0; i < 2; ++i)
+                dma16(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + (c % QBUFS) * QBYTES + s * SLAB + (wave + 4 * i) * 1024);
     };
-    auto issue_wa = [&](int c, int sa, int buf) {  // W2c rows [c * NC, +128), k-slab sa
-        const char* base = WAb + ((size_t)(c * NC) * p.ldw2c + sa * 64) * 2;
+    auto issue_wa = [&](int c) {  // W2c rows [c * NC, + NC), all KSA k-slabs -> slot A
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dma16(base + (size_t)(16 * i) * p.ldw2c * 2 + off_wa, lds + WS_OFF + buf * WSB + (lw + 2 * i) * 1024);
+        for (int s = 0; s < KSA; ++s) {
+            const char* base = WAb + ((size_t)(c * NC) * p.ldw2c + s * 64) * 2;
+#pragma unroll
+            for (int i = 0; i < NC / 32; ++i)
+                dma16(base + (size_t)(32 * i) * p.ldw2c * 2 + off_wa, lds + WA_OFF + s * WA_SLAB + (wave + 4 * i) * 1024);
+        }
     };
-    auto issue_wb = [&](int c, int sb, int buf) {  // W2a' rows [0, CP), k-slab (c * NC + sb * 64)
-        const char* base = WBb + (c * NC + sb * 64) * 2;
+    auto issue_wb = [&](int c) {  // W2a' rows [0, CP), k-slabs of chunk c -> slot B
 #pragma unroll
-        for (int i = 0; i < CP / 16; ++i) dma16(base + (size_t)(16 * i) * p.ldw2a * 2 + off_wb, lds + WS_OFF + buf * WSB + (lw + 2 * i) * 1024);
+        for (int s = 0; s < KSB; ++s) {
+            const char* base = WBb + (c * NC + s * 64) * 2;
+#pragma unroll
+            for (int i = 0; i < CP / 32; ++i)
+                dma16(base + (size_t)(32 * i) * p.ldw2a * 2 + off_wb, lds + WB_OFF + s * WB_SLAB + (wave + 4 * i) * 1024);
+        }
     };
 
     // ---- fragment addressing (byte offsets inside a slab)
@@ -126,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     const int wn = wave & 1;   // channel half
     const int ar = wm * 32 + (lane & 31);
     const int a_off = ar * 128, a_x = (ar >> 1) & 7;
-    int wa_off[2], wa_x[2], wb_off[NTB], wb_x[NTB];
+    int wa_off[NTA], wa_x[NTA], wb_off[NTB], wb_x[NTB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NTA; ++j) {
+        const int r = wn * (NC / 2) + j * 32 + (lane & 31);
         wa_off[j] = r * 128;
         wa_x[j] = (r >> 1) & 7;
     }
@@ -146,58 +180,52 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
 #pragma unroll
         for (int e = 0; e < 16; ++e) accB[j][e] = 0.f;
 
-    // ---- prologue
-    if (w_loader) {
-        issue_wa(0, 0, 0);
-    } else {
-        issue_at();
-        issue_res(0, 0);
-    }
+    // ---- prologue: everything the first chunks need, at once.  The issue ORDER below is what the counted waits rely on:
+    //      t2 tile, res(0), A(0), B(0), res(1 .. QBUFS-1); then per chunk c: [barrier 1] B(c), res(c - 1 + QBUFS) (c > 0)
+    //      [barrier 2] A(c + 1), t3 stores of chunk c.
+    issue_at();
+    issue_res(0);
+    issue_wa(0);
+    issue_wb(0);
+#pragma unroll
+    for (int c = 1; c < QBUFS; ++c) issue_res(c);
 
-    int w = 0;  // weight-slab counter (compile-time after unrolling): buffer = w & 1
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int qb = c & 1;
-        f32x16 accA[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) accA[j][e] = 0.f;
+        const int qb = c % QBUFS;
+        // ---- barrier 1: the GEMM-A weights and the residual of this chunk (and the t2 tile when c == 0) have landed -- the youngest of
+        //      them is A(c); what was issued after it stays in flight -- and every wave is out of chunk c - 1.
+        wait_dma_leaving(c == 0 ? WI + (QBUFS - 1) * RI : ST, full_tile);
+        lds_barrier();
+        if (c > 0) issue_wb(c);                                      // slot B: GEMM-B of chunk c - 1 is done
+        if (c > 0 && c - 1 + QBUFS < NCH) issue_res(c - 1 + QBUFS);  // Q[(c - 1) % QBUFS]: read and stored
 
         // ================= GEMM-A: accA[n][m] = W2c[chunk c] . t2 tile
+        f32x16 accA[NTA];
 #pragma unroll
-        for (int sa = 0; sa < KSA; ++sa) {
-            const int buf = w & 1;
-            // waves 0-1: their weight slab has landed.  Waves 2-3: at the first barrier (t2 tile) and at the LAST GEMM-A barrier of
-            // a chunk (its residual, issued one chunk ago) -- never behind a DMA they have only just issued.
-            if (w_loader || (c == 0 && sa == 0) || sa == KSA - 1) wait_dma();
-            lds_barrier();
-            if (w_loader) {
-                if (sa + 1 < KSA) issue_wa(c, sa + 1, buf ^ 1);
-                else issue_wb(c, 0, buf ^ 1);
-            } else if (sa == KSA - 1 && c + 1 < NCH) {
-                issue_res(c + 1, qb ^ 1);  // its buffer was last read in chunk c - 1
-            }
+        for (int j = 0; j < NTA; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accA[j][e] = 0.f;
+#pragma unroll
+        for (int sa = 0; sa < KSA; ++sa)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int lc = 2 * g + hi;
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(lds + AT_OFF + sa * SLAB + a_off + ((lc ^ a_x) << 4));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16x8 fw = *reinterpret_cast<const bf16x8*>(lds + WS_OFF + buf * WSB + wa_off[j] + ((lc ^ wa_x[j]) << 4));
+                for (int j = 0; j < NTA; ++j) {
+                    const bf16x8 fw = *reinterpret_cast<const bf16x8*>(lds + WA_OFF + sa * WA_SLAB + wa_off[j] + ((lc ^ wa_x[j]) << 4));
                     accA[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fa, accA[j], 0, 0, 0);
                 }
             }
-            ++w;
-        }
 
         // ================= epilogue-A, in place on Q[qb]: q = bf16(relu(acc * scale + shift + q))
-        // lane: pixel row ar, channels nb + 8 g + 4 hi + (0..3) of block j  ->  8 bytes of the slab row
+        // lane: pixel row ar, channels nl0 + 8 g + 4 hi + (0..3) of block j  ->  8 bytes of the slab row
         {
             unsigned char* Q = lds + Q_OFF + qb * QBYTES;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int nl0 = wn * 64 + j * 32;  // first channel of the block inside the chunk (wave-uniform)
+            for (int j = 0; j < NTA; ++j) {
+                const int nl0 = wn * (NC / 2) + j * 32;  // first channel of the block inside the chunk (wave-uniform)
                 cfloat_p scp = (cfloat_p)(p.scaleA + c * NC + nl0);
                 cfloat_p shp = (cfloat_p)(p.shiftA + c * NC + nl0);
                 unsigned char* Qs = Q + (nl0 >> 6) * SLAB + a_off;
@@ -220,16 +248,20 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
                 }
             }
         }
-        lds_barrier();  // Q[qb] is now the t3 tile of this chunk (LDS writes only; the DMAs in flight are not waited for)
+        // ---- barrier 2: Q[qb] is the t3 tile of this chunk; the GEMM-B weights have landed (only residual chunks are younger); GEMM-A
+        //      is done everywhere
+        wait_dma_leaving(c == 0 ? (QBUFS - 1) * RI : (c - 1 + QBUFS < NCH ? RI : 0), full_tile);
+        lds_barrier();
+        if (c + 1 < NCH) issue_wa(c + 1);  // slot A is free
 
-        // ================= t3 row stores (waves 2-3: they never wait on a fresh DMA) + GEMM-B partial sums
-        if (!w_loader) {
+        // ================= t3 row stores + GEMM-B partial sums
+        {
             const unsigned char* Q = lds + Q_OFF + qb * QBYTES;
-            const int tt = t - 128;
+            constexpr int UPR = NC / 8;  // 16-B units per row
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int idx = pass * 128 + tt;  // 1024 units of 16 B: row = idx / 16, unit u = idx % 16
-                const int r = idx >> 4, u = idx & 15;
+            for (int pass = 0; pass < (BM * UPR) / 256; ++pass) {
+                const int idx = pass * 256 + t;
+                const int r = idx / UPR, u = idx - r * UPR;
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(Q + (u >> 3) * SLAB + r * 128 + (((u & 7) ^ ((r >> 1) & 7)) << 4));
                 const int m = m0 + r;
                 if (m < p.M) *reinterpret_cast<bf16x8*>(p.t3 + (size_t)m * C4 + c * NC + u * 8) = v;
@@ -237,13 +269,6 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
         }
 #pragma unroll
         for (int sb = 0; sb < KSB; ++sb) {
-            const int buf = w & 1;
-            if (w_loader) wait_dma();
-            lds_barrier();
-            if (w_loader) {
-                if (sb + 1 < KSB) issue_wb(c, sb + 1, buf ^ 1);
-                else if (c + 1 < NCH) issue_wa(c + 1, 0, buf ^ 1);
-            }
             const unsigned char* Q = lds + Q_OFF + qb * QBYTES + sb * SLAB;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -251,16 +276,15 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(Q + a_off + ((lc ^ a_x) << 4));
 #pragma unroll
                 for (int j = 0; j < NTB; ++j) {
-                    const bf16x8 fw = *reinterpret_cast<const bf16x8*>(lds + WS_OFF + buf * WSB + wb_off[j] + ((lc ^ wb_x[j]) << 4));
+                    const bf16x8 fw = *reinterpret_cast<const bf16x8*>(lds + WB_OFF + sb * WB_SLAB + wb_off[j] + ((lc ^ wb_x[j]) << 4));
                     accB[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fa, accB[j], 0, 0, 0);
                 }
             }
-            ++w;
         }
     }
 
     // ================= epilogue-B: u1 = bf16(relu(accB * scale' + shift')) -> LDS (the t2 tile's space, slab layout) -> 16-B row stores
-    lds_barrier();  // every wave is out of the last GEMM-B slab (and GEMM-A finished a chunk ago): AT is free
+    // (GEMM-A last read the t2 tile before barrier 2 of the last chunk: its space is free)
     {
         unsigned char* U = lds + AT_OFF;
 #pragma unroll
@@ -300,10 +324,10 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     }
 }
 
-template <int C, int CP>
+template <int C, int CP, int NC>
 hipError_t launch_chain(const ChainArgs& p, hipStream_t st) {
     const int grid = (p.M + 63) / 64;
-    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP>), dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP, NC>), dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -316,13 +340,13 @@ hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, hipS
     if (p.M <= 0 || !p.t2 || !p.res || !p.w2c || !p.w2a || !p.t3 || !p.u1 || !p.scaleA || !p.shiftA || !p.scaleB || !p.shiftB) return hipErrorInvalidValue;
     if (p.ldw2c < C || p.ldw2a < C4 || (p.ldw2c % 8) != 0 || (p.ldw2a % 8) != 0) return hipErrorInvalidValue;
     if ((((uintptr_t)p.t2 | (uintptr_t)p.res | (uintptr_t)p.w2c | (uintptr_t)p.w2a | (uintptr_t)p.t3 | (uintptr_t)p.u1) & 15) != 0) return hipErrorInvalidValue;
-    if (C == 64) return launch_chain<64, 64>(p, st);
-    return launch_chain<128, 128>(p, st);
+    if (C == 64) return launch_chain<64, 64, 128>(p, st);
+    return launch_chain<128, 128, 64>(p, st);
 }
 
 // resident workgroups per CU of the two instantiations (the design needs 2): out[0] C = 64, out[1] C = 128
 hipError_t hpe_chain_bf16_occupancy(int out[2]) {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<64, 64>), 256, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<64, 64, 128>), 256, 0);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<128, 128>), 256, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<128, 128, 64>), 256, 0);
 }
