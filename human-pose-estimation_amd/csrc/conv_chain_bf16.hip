@@ -71,21 +71,25 @@ __device__ __forceinline__ void wait_dma_leaving(int n, bool exact_counts) {
     }
 }
 
-// C = channels of t2 (K of the expand GEMM), 4C = channels of t3, CP = output channels of the reduce GEMM, NC = channels per chunk
-template <int C, int CP, int NC>
+// C = channels of t2, 4C = channels of t3, CP = output channels of the reduce GEMM, NC = channels per chunk.
+// C2 > 0: the conv_block form -- no residual; the expand GEMM has a second A source x2 [M, C2] (the block input, stride 1) behind t2 along
+// k, i.e. branch2c and the projection shortcut branch1 as one GEMM over [t2 | x2] with the BN scales folded into the weights (GEMM_DUAL of
+// conv_gemm_bf16.hip), followed by the next block's branch2a.
+template <int C, int CP, int NC, int C2>
 __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
     constexpr int BM = 64, C4 = 4 * C;
-    constexpr int KSA = C / 64, KSB = NC / 64, NCH = C4 / NC;
+    constexpr bool HAS_RES = C2 == 0;
+    constexpr int KSA = (C + C2) / 64, KSB = NC / 64, NCH = C4 / NC;
     constexpr int SLAB = BM * 128;  // bytes of one [64 rows x 64 bf16] slab
     constexpr int QBYTES = KSB * SLAB, QBUFS = 32768 / QBYTES;
     constexpr int WA_SLAB = NC * 128, WB_SLAB = CP * 128;  // one k-slab of the GEMM-A / GEMM-B weights of a chunk
     constexpr int AT_OFF = 0, Q_OFF = KSA * SLAB, WA_OFF = Q_OFF + QBUFS * QBYTES, WB_OFF = WA_OFF + KSA * WA_SLAB;
-    constexpr int LDS_BYTES = WB_OFF + KSB * WB_SLAB;
+    constexpr int LDS_BYTES = WB_OFF + 16384;
     constexpr int NTA = NC / 64, NTB = CP / 64;  // 32-wide channel blocks per wave (a wave owns half the chunk / half of C')
     // vector-memory instructions per wave of each group (every wave issues a quarter of every group)
-    constexpr int RI = KSB * 2, WI = 4, ST = NC / 32;  // residual chunk, one weight slot, t3 stores of a chunk
-    static_assert(C % 64 == 0 && C4 % NC == 0 && (NC == 64 || NC == 128) && (CP == 64 || CP == 128), "geometry");
-    static_assert(KSA * WA_SLAB == 16384 && KSB * WB_SLAB == 16384 && QBUFS * QBYTES == 32768 && QBUFS <= NCH, "slot sizes");
+    constexpr int RI = HAS_RES ? KSB * 2 : 0, WIB = KSB * CP / 32, ST = NC / 32;  // residual chunk, GEMM-B weight slot, t3 stores of a chunk
+    static_assert(C % 64 == 0 && C2 % 64 == 0 && C4 % NC == 0 && (NC == 64 || NC == 128) && (CP == 64 || CP == 128), "geometry");
+    static_assert(KSA * WA_SLAB == 16384 && KSB * WB_SLAB <= 16384 && QBUFS * QBYTES == 32768 && QBUFS <= NCH, "slot sizes");
     static_assert(KSA * SLAB >= (CP / 64) * SLAB, "the u1 tile reuses the t2 tile's space");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 
@@ -108,13 +112,14 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     // ((row >> 1) & 7) = (4 ii + (drow >> 1)) & 7 depends on the parity of ii only, i.e. on the wave.
     const int r0 = 8 * wave + drow;
     const unsigned swz_a = (((lane & 7) ^ ((r0 >> 1) & 7)) * 8) * 2;
-    unsigned off_t2[2], off_res[2];  // activation rows r0, r0 + 32, clamped to M - 1 on the last tile
+    unsigned off_t2[2], off_res[2], off_x2[2];  // activation rows r0, r0 + 32, clamped to M - 1 on the last tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int m = m0 + r0 + 32 * i;
         if (m >= p.M) m = p.M - 1;
         off_t2[i] = (unsigned)m * (C * 2) + swz_a;
         off_res[i] = (unsigned)m * (C4 * 2) + swz_a;
+        off_x2[i] = (unsigned)m * (C2 * 2) + swz_a;
     }
     const unsigned off_wa = (unsigned)r0 * (unsigned)(p.ldw2c * 2) + swz_a;  // weight rows r0 + 32 i: the row step is wave-uniform
     const unsigned off_wb = (unsigned)r0 * (unsigned)(p.ldw2a * 2) + swz_a;
@@ -123,11 +128,15 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     const char* WAb = reinterpret_cast<const char*>(p.w2c);
     const char* WBb = reinterpret_cast<const char*>(p.w2a);
 
-    auto issue_at = [&]() {  // t2 tile -> AT: KSA slabs
+    const char* X2b = reinterpret_cast<const char*>(p.x2);
+    auto issue_at = [&]() {  // [t2 | x2] tile -> AT: KSA slabs
 #pragma unroll
         for (int s = 0; s < KSA; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dma16(T2b + s * 128 + off_t2[i], lds + AT_OFF + s * SLAB + (wave + 4 * i) * 1024);
+            for (int i = 0; i < 2; ++i) {
+                const char* src = s < C / 64 ? T2b + s * 128 + off_t2[i] : X2b + (s - C / 64) * 128 + off_x2[i];
+                dma16(src, lds + AT_OFF + s * SLAB + (wave + 4 * i) * 1024);
+            }
     };
     auto issue_res = [&](int c) {  // residual chunk c -> Q[c % QBUFS]: KSB slabs
 #pragma unroll
@@ -184,21 +193,23 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     //      t2 tile, res(0), A(0), B(0), res(1 .. QBUFS-1); then per chunk c: [barrier 1] B(c), res(c - 1 + QBUFS) (c > 0)
     //      [barrier 2] A(c + 1), t3 stores of chunk c.
     issue_at();
-    issue_res(0);
+    if (HAS_RES) issue_res(0);
     issue_wa(0);
     issue_wb(0);
+    if (HAS_RES) {
 #pragma unroll
-    for (int c = 1; c < QBUFS; ++c) issue_res(c);
+        for (int c = 1; c < QBUFS; ++c) issue_res(c);
+    }
 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int qb = c % QBUFS;
         // ---- barrier 1: the GEMM-A weights and the residual of this chunk (and the t2 tile when c == 0) have landed -- the youngest of
         //      them is A(c); what was issued after it stays in flight -- and every wave is out of chunk c - 1.
-        wait_dma_leaving(c == 0 ? WI + (QBUFS - 1) * RI : ST, full_tile);
+        wait_dma_leaving(c == 0 ? WIB + (QBUFS - 1) * RI : ST, full_tile);
         lds_barrier();
         if (c > 0) issue_wb(c);                                      // slot B: GEMM-B of chunk c - 1 is done
-        if (c > 0 && c - 1 + QBUFS < NCH) issue_res(c - 1 + QBUFS);  // Q[(c - 1) % QBUFS]: read and stored
+        if (HAS_RES && c > 0 && c - 1 + QBUFS < NCH) issue_res(c - 1 + QBUFS);  // Q[(c - 1) % QBUFS]: read and stored
 
         // ================= GEMM-A: accA[n][m] = W2c[chunk c] . t2 tile
         f32x16 accA[NTA];
@@ -233,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     unsigned char* q = Qs + (((kc0 + g) ^ a_x) << 4) + hi * 8;
-                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(q);
+                    bf16x4 rv = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    if (HAS_RES) rv = *reinterpret_cast<const bf16x4*>(q);
                     bf16x4 o;
                     // two s_load_dwordx4 per vector (channels 8 g .. + 3 for lanes 0-31, 8 g + 4 .. + 7 for lanes 32-63), selected per element
                     const f32x4 sc_lo = *reinterpret_cast<cf32x4_p>(scp + 8 * g), sc_hi = *reinterpret_cast<cf32x4_p>(scp + 8 * g + 4);
@@ -324,29 +336,38 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
     }
 }
 
-template <int C, int CP, int NC>
+template <int C, int CP, int NC, int C2>
 hipError_t launch_chain(const ChainArgs& p, hipStream_t st) {
     const int grid = (p.M + 63) / 64;
-    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP, NC>), dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP, NC, C2>), dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
-bool hpe_chain_bf16_supported(int C, int C4, int CP) { return C4 == 4 * C && CP == C && (C == 64 || C == 128); }
-
-hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, hipStream_t st) {
-    if (!hpe_chain_bf16_supported(C, C4, CP)) return hipErrorInvalidValue;
-    if (p.M <= 0 || !p.t2 || !p.res || !p.w2c || !p.w2a || !p.t3 || !p.u1 || !p.scaleA || !p.shiftA || !p.scaleB || !p.shiftB) return hipErrorInvalidValue;
-    if (p.ldw2c < C || p.ldw2a < C4 || (p.ldw2c % 8) != 0 || (p.ldw2a % 8) != 0) return hipErrorInvalidValue;
-    if ((((uintptr_t)p.t2 | (uintptr_t)p.res | (uintptr_t)p.w2c | (uintptr_t)p.w2a | (uintptr_t)p.t3 | (uintptr_t)p.u1) & 15) != 0) return hipErrorInvalidValue;
-    if (C == 64) return launch_chain<64, 64, 128>(p, st);
-    return launch_chain<128, 128, 64>(p, st);
+// C2 = 0: identity block (residual); C2 > 0: conv_block with a stride-1 projection shortcut over C2 input channels (stage 2)
+bool hpe_chain_bf16_supported(int C, int C4, int CP, int C2) {
+    if (C4 != 4 * C || CP != C) return false;
+    return C2 == 0 ? (C == 64 || C == 128) : (C == 64 && C2 == 64);
 }
 
-// resident workgroups per CU of the two instantiations (the design needs 2): out[0] C = 64, out[1] C = 128
-hipError_t hpe_chain_bf16_occupancy(int out[2]) {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<64, 64, 128>), 256, 0);
+hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, int C2, hipStream_t st) {
+    if (!hpe_chain_bf16_supported(C, C4, CP, C2)) return hipErrorInvalidValue;
+    if (p.M <= 0 || !p.t2 || !p.w2c || !p.w2a || !p.t3 || !p.u1 || !p.scaleA || !p.shiftA || !p.scaleB || !p.shiftB) return hipErrorInvalidValue;
+    if (C2 == 0 ? !p.res : !p.x2) return hipErrorInvalidValue;
+    if (p.ldw2c < C + C2 || p.ldw2a < C4 || (p.ldw2c % 8) != 0 || (p.ldw2a % 8) != 0) return hipErrorInvalidValue;
+    if ((((uintptr_t)p.t2 | (uintptr_t)p.res | (uintptr_t)p.x2 | (uintptr_t)p.w2c | (uintptr_t)p.w2a | (uintptr_t)p.t3 | (uintptr_t)p.u1) & 15) != 0)
+        return hipErrorInvalidValue;
+    if (C2 > 0) return launch_chain<64, 64, 64, 64>(p, st);
+    if (C == 64) return launch_chain<64, 64, 128, 0>(p, st);
+    return launch_chain<128, 128, 64, 0>(p, st);
+}
+
+// resident workgroups per CU of the three instantiations (the design needs 2): out[0] C = 64, out[1] C = 128, out[2] conv_block form
+hipError_t hpe_chain_bf16_occupancy(int out[3]) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<64, 64, 128, 0>), 256, 0);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<128, 128, 64>), 256, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<128, 128, 64, 0>), 256, 0);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[2], reinterpret_cast<const void*>(chain_expand_reduce_bf16_kernel<64, 64, 64, 64>), 256, 0);
 }

@@ -460,33 +460,52 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
 }
 
 // the bf16 identity-block pair branch2c (idx i2c, + residual + ReLU) -> next block's branch2a (idx i2c + 1) as one launch
+// `first`: the conv_block form -- branch2c + the projection shortcut branch1 (idx i2c + 1, stride 1: stage 2 only) as the dual-source GEMM,
+// chained with the next block's branch2a (idx i2c + 2); bit 2 of chain_fuse
 bool use_chain(const hpe_ctx* c, int stg, int i2c, bool first, bool has_next) {
-    if (!c->bf16 || first || !has_next || !((c->chain_fuse >> stg) & 1)) return false;
+    if (!c->bf16 || !has_next) return false;
     const ConvSpec& s2 = specs()[i2c];
+    if (first) {
+        const ConvSpec& s1 = specs()[i2c + 1];
+        const ConvSpec& sn = specs()[i2c + 2];
+        return stg == 0 && (c->chain_fuse & 4) && c->conv[i2c].w_dual && s1.stride == 1 && s1.hin == s2.hin && sn.kh == 1 && sn.stride == 1 &&
+               sn.cin == s2.cout && c->conv[i2c].k_dual == s2.cin + s1.cin && hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout, s1.cin);
+    }
+    if (!((c->chain_fuse >> stg) & 1)) return false;
     const ConvSpec& sn = specs()[i2c + 1];
-    return sn.kh == 1 && sn.stride == 1 && sn.cin == s2.cout && hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout);
+    return sn.kh == 1 && sn.stride == 1 && sn.cin == s2.cout && hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout, 0);
 }
 
-hipError_t run_chain(hpe_ctx* c, int i2c, const float* t2, const float* res, int B, float* t3, float* u1, hipStream_t st) {
+// res: the block input -- the residual of an identity block, the second A source of a conv_block
+hipError_t run_chain(hpe_ctx* c, int i2c, bool first, const float* t2, const float* res, int B, float* t3, float* u1, hipStream_t st) {
     const ConvSpec& s2 = specs()[i2c];
-    const ConvSpec& sn = specs()[i2c + 1];
+    const int inext = i2c + (first ? 2 : 1);
+    const ConvSpec& sn = specs()[inext];
     const ConvLayer& L2 = c->conv[i2c];
-    const ConvLayer& Ln = c->conv[i2c + 1];
+    const ConvLayer& Ln = c->conv[inext];
     ChainArgs p{};
     p.t2 = reinterpret_cast<const __bf16*>(t2);
-    p.res = reinterpret_cast<const __bf16*>(res);
-    p.w2c = reinterpret_cast<const __bf16*>(L2.w);
+    if (first) {
+        p.x2 = reinterpret_cast<const __bf16*>(res);
+        p.w2c = reinterpret_cast<const __bf16*>(L2.w_dual);
+        p.scaleA = c->ones;
+        p.shiftA = L2.shift_dual;
+        p.ldw2c = L2.k_dual;
+    } else {
+        p.res = reinterpret_cast<const __bf16*>(res);
+        p.w2c = reinterpret_cast<const __bf16*>(L2.w);
+        p.scaleA = L2.scale;
+        p.shiftA = L2.shift;
+        p.ldw2c = L2.k_pad;
+    }
     p.w2a = reinterpret_cast<const __bf16*>(Ln.w);
-    p.scaleA = L2.scale;
-    p.shiftA = L2.shift;
     p.scaleB = Ln.scale;
     p.shiftB = Ln.shift;
     p.t3 = reinterpret_cast<__bf16*>(t3);
     p.u1 = reinterpret_cast<__bf16*>(u1);
     p.M = B * s2.hout * s2.hout;
-    p.ldw2c = L2.k_pad;
     p.ldw2a = Ln.k_pad;
-    return hpe_launch_chain_bf16(p, s2.cin, s2.cout, sn.cout, st);
+    return hpe_launch_chain_bf16(p, s2.cin, s2.cout, sn.cout, first ? specs()[i2c + 1].cin : 0, st);
 }
 
 hipError_t run_dense(hpe_ctx* c, const float* x, int lda, int M, int K, const float* w, int w_rows, int N, const float* scale,
@@ -587,8 +606,14 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
                 // launch; the 4C-wide sum is written once and not read back (timed as layer i2c; the next branch2a then shows 0)
                 const bool t2 = c->timing >= 2;
                 if (t2) HIPE(hipEventRecord(c->cev0[i2c], st));
-                HIPE(run_chain(c, i2c, T2, cur, B, nxt, T1, st));
-                if (t2) HIPE(hipEventRecord(c->cev1[i2c], st));
+                HIPE(run_chain(c, i2c, first, T2, cur, B, nxt, T1, st));
+                if (t2) {
+                    HIPE(hipEventRecord(c->cev1[i2c], st));
+                    if (first) {  // the projection shortcut is inside the launch
+                        HIPE(hipEventRecord(c->cev0[i1], st));
+                        HIPE(hipEventRecord(c->cev1[i1], st));
+                    }
+                }
                 have_2a = true;
             } else if (first && c->conv[i2c].w_dual) {
                 // conv_block: expand convolution + projection shortcut + add + ReLU as one dual-source GEMM (timed as layer i2c)
@@ -911,7 +936,7 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
         c->wino4_ksplit = opt(c->cfg.wino4_ksplit, "HPE_WINO4_KSPLIT", 1);
-        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 3) & 3) : 0;
+        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 7) & 7) : 0;
         c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
@@ -1671,17 +1696,21 @@ int hpe_debug_chain(hpe_ctx* c, int idx2c, const float* t2, const float* residua
     int rc = check_ready(c, B, NEED_ENC);
     if (rc) return rc;
     if (!c->bf16) return fail(HPE_ERR_STATE, "hpe_debug_chain works on bf16 contexts only");
-    if (idx2c < 1 || idx2c + 1 >= HPE_NUM_CONV || !t2 || !residual || !t3 || !u1) return fail(HPE_ERR_INVALID, "bad argument");
+    if (idx2c < 1 || idx2c + 2 >= HPE_NUM_CONV || !t2 || !residual || !t3 || !u1) return fail(HPE_ERR_INVALID, "bad argument");
     const ConvSpec& s2 = specs()[idx2c];
-    const ConvSpec& sn = specs()[idx2c + 1];
-    if (s2.kh != 1 || s2.cout != 4 * s2.cin || sn.kh != 1 || sn.stride != 1 || sn.cin != s2.cout || !hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout))
+    // the conv_block form when idx2c is the branch2c of a block's first unit (its branch1 follows in the layer table)
+    const bool first = specs()[idx2c + 1].kh == 1 && specs()[idx2c + 1].cout == s2.cout && strstr(specs()[idx2c + 1].name, "branch1") != nullptr;
+    const ConvSpec& sn = specs()[idx2c + (first ? 2 : 1)];
+    const int C2 = first ? specs()[idx2c + 1].cin : 0;
+    if (s2.kh != 1 || s2.cout != 4 * s2.cin || sn.kh != 1 || sn.stride != 1 || sn.cin != s2.cout || !hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout, C2) ||
+        (first && (!c->conv[idx2c].w_dual || specs()[idx2c + 1].stride != 1)))
         return fail(HPE_ERR_INVALID, "hpe_debug_chain: idx2c must be the branch2c of a stage-2 / stage-3 block that is followed by an identity block");
     DeviceGuard g(c->cfg.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long M = (long)B * s2.hout * s2.hout;
     HIP_TRY(hpe_launch_f32_to_bf16(t2, c->T2, M * s2.cin, st));
-    HIP_TRY(hpe_launch_f32_to_bf16(residual, c->X0, M * s2.cout, st));
-    HIP_TRY(run_chain(c, idx2c, c->T2, c->X0, B, c->X1, c->T1, st));
+    HIP_TRY(hpe_launch_f32_to_bf16(residual, c->X0, M * (first ? C2 : s2.cout), st));
+    HIP_TRY(run_chain(c, idx2c, first, c->T2, c->X0, B, c->X1, c->T1, st));
     HIP_TRY(hpe_launch_bf16_to_f32(c->X1, t3, M * s2.cout, st));
     HIP_TRY(hpe_launch_bf16_to_f32(c->T1, u1, M * sn.cout, st));
     if (occupancy) HIP_TRY(hpe_chain_bf16_occupancy(occupancy));

@@ -84,7 +84,8 @@ hipError_t hpe_launch_gemm_bf16_p8(GemmArgs p, int mode, hipStream_t st);
 // first 1x1 of identity block i + 1); all tensors bf16, row-major [M, channels], weights packed [n][k]
 struct ChainArgs {
     const __bf16* t2;   // [M, C]
-    const __bf16* res;  // [M, 4C]
+    const __bf16* res;  // [M, 4C]  (identity block; nullptr in the conv_block form)
+    const __bf16* x2;   // [M, C2]  conv_block form: the block input, second A source of the expand GEMM (nullptr otherwise)
     const __bf16* w2c;  // [4C][ldw2c]
     const __bf16* w2a;  // [C'][ldw2a]
     const float *scaleA, *shiftA;  // [4C]
@@ -93,9 +94,9 @@ struct ChainArgs {
     __bf16* u1;  // [M, C']
     int M, ldw2c, ldw2a;
 };
-bool hpe_chain_bf16_supported(int C, int C4, int CP);
-hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, hipStream_t st);
-hipError_t hpe_chain_bf16_occupancy(int out[2]);
+bool hpe_chain_bf16_supported(int C, int C4, int CP, int C2);
+hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, int C2, hipStream_t st);
+hipError_t hpe_chain_bf16_occupancy(int out[3]);
 hipError_t hpe_launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);  // round to nearest even
 hipError_t hpe_launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t st);
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);

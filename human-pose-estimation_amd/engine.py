@@ -454,15 +454,17 @@ class HpeEngine(object):
     def debug_chain(self, idx2c, t2, residual):
         """bf16 contexts: res*_branch2c (+ residual + ReLU) and the next block's res*_branch2a (+ ReLU) as the one launch of
         conv_chain_bf16.hip.  Returns (t3 [B,H,H,4C], u1 [B,H,H,C], resident workgroups per CU of the two instantiations)."""
-        s, sn = CONV_SPECS[idx2c], CONV_SPECS[idx2c + 1]
+        s = CONV_SPECS[idx2c]
+        first = CONV_SPECS[idx2c + 1].name.endswith("branch1")  # conv_block form: `residual` is the block input
+        sn = CONV_SPECS[idx2c + (2 if first else 1)]
         t2 = _require_cuda_tensor(t2, "t2", (s.hin, s.hin, s.cin))
-        residual = _require_cuda_tensor(residual, "residual", (s.hout, s.hout, s.cout))
+        residual = _require_cuda_tensor(residual, "residual", (s.hout, s.hout, CONV_SPECS[idx2c + 1].cin if first else s.cout))
         B = t2.shape[0]
         t3 = self._new(B, s.hout, s.hout, s.cout)
         u1 = self._new(B, sn.hout, sn.hout, sn.cout)
-        occ = (C.c_int * 2)()
+        occ = (C.c_int * 3)()
         _lib.check(self.lib.hpe_debug_chain(self._h, idx2c, t2.data_ptr(), residual.data_ptr(), B, t3.data_ptr(), u1.data_ptr(), occ, self._stream()))
-        return t3, u1, (occ[0], occ[1])
+        return t3, u1, (occ[0], occ[1], occ[2])
 
     def debug_stem(self, images, rows_per_strip=0):
         images = _require_cuda_tensor(images, "images", (224, 224, 3))

@@ -82,7 +82,8 @@ typedef struct HpeConfig {
                             *                      (1); 0 = never (one summation order per output whatever the batch) */
     int chain_fuse;        /* HPE_CHAIN            bf16 encoder: stages (1 = stage 2, 2 = stage 3) whose identity blocks run res*_branch2c + add +
                             *                      ReLU and the NEXT block's res*_branch2a + ReLU as one launch: the 4C-wide block output is
-                            *                      written once and not read back (3); same bf16 rounding points as the two launches */
+                            *                      written once and not read back; 4 = the same for res2a (branch2c + branch1 + add + ReLU, the
+                            *                      dual-source GEMM, + res2b_branch2a) (7); same bf16 rounding points as the separate launches */
 } HpeConfig;
 
 /* defaults: struct_size = sizeof(HpeConfig), device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1.
@@ -230,8 +231,9 @@ int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float
                    void* stream);
 /* bf16 contexts: the chained launch of conv_chain_bf16.hip alone.  idx2c = res{2,3}{b..}_branch2c of a block that is followed by an
  * identity block: t2_dev [B,H,H,C], residual_dev [B,H,H,4C] (rounded to bf16 on the way in) -> t3_dev [B,H,H,4C] =
- * relu(bn(conv2c(t2)) + residual) and u1_dev [B,H,H,C] = relu(bn(conv2a_next(t3))), both widened to float.  occupancy (host, optional,
- * 2 ints): resident workgroups per CU of the two instantiations (the design needs 2). */
+ * relu(bn(conv2c(t2)) + residual) and u1_dev [B,H,H,C] = relu(bn(conv2a_next(t3))), both widened to float.  idx2c = res2a_branch2c: the
+ * conv_block form, residual_dev is the block INPUT [B,56,56,64] and t3 = relu(bn(conv2c(t2)) + bn(conv1(input))).  occupancy (host,
+ * optional, 3 ints): resident workgroups per CU of the three instantiations (the design needs 2). */
 int hpe_debug_chain(hpe_ctx* ctx, int idx2c, const float* t2_dev, const float* residual_dev, int B, float* t3_dev, float* u1_dev,
                     int* occupancy, void* stream);
 /* The fused stem kernel alone (conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + MaxPooling2D(3,2) of the Keras ResNet50,

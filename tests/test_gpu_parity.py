@@ -1003,9 +1003,9 @@ def test_bf16_p8_encoder_matches_round2_encoder(engines_bf16_old_and_p8, assets)
 # ------------------------------------------------------------------------------------------- bf16 chained 1x1 launches (round 4)
 @pytest.fixture(scope="module")
 def engines_bf16_chain_off_on(assets):
-    """Two bf16 encoder contexts: every layer its own launch (chain_fuse=0) and the identity blocks of stages 2-3 with branch2c + the next
-    block's branch2a as one launch (chain_fuse=3, the default)."""
-    made = [encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=0), encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=3)]
+    """Two bf16 encoder contexts: every layer its own launch (chain_fuse=0) and the blocks of stages 2-3 (identity blocks, and the conv_block
+    res2a) with branch2c + the next block's branch2a as one launch (chain_fuse=7, the default)."""
+    made = [encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=0), encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=7)]
     yield made
     for e in made:
         e.close()
@@ -1027,8 +1027,8 @@ def test_bf16_chain_matches_oracle_and_two_launches(engines_bf16_chain_off_on, a
     t2[0, 0, 0, :] = 20.0
     t3, u1, occ = on.debug_chain(idx, gpu(t2), gpu(x))
     t3, u1 = cpu(t3), cpu(u1)
-    print("chain kernel: resident workgroups per CU (C = 64, C = 128): %s" % (occ,))
-    assert occ[0] >= 2 and occ[1] >= 2, occ
+    print("chain kernel: resident workgroups per CU (C = 64, C = 128, conv_block form): %s" % (occ,))
+    assert min(occ) >= 2, occ
     # (ii) the two launches
     t3_two = cpu(off.debug_conv(idx, gpu(t2), residual=gpu(x), relu=True))
     u1_two = cpu(off.debug_conv(idx + 1, gpu(t3_two), relu=True))
@@ -1043,6 +1043,39 @@ def test_bf16_chain_matches_oracle_and_two_launches(engines_bf16_chain_off_on, a
     lin = O.conv2d_nhwc(_bf16_round(t2), _bf16_round(p[s.name + "/kernel"]), p[s.name + "/bias"], 1, 0, dtype=np.float64) * sc + sh
     ref3 = np.maximum(lin + _bf16_round(x).astype(np.float64), 0)
     assert rel(t3, ref3) < ulp, rel(t3, ref3)
+    lin = O.conv2d_nhwc(_bf16_round(ref3), _bf16_round(p[sn.name + "/kernel"]), p[sn.name + "/bias"], 1, 0, dtype=np.float64) * scn + shn
+    ref1 = np.maximum(lin, 0)
+    assert rel(u1, ref1) < 2 * ulp, rel(u1, ref1)
+    assert float(np.linalg.norm(u1 - ref1) / np.linalg.norm(ref1)) < 2.5e-3
+
+
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_bf16_chain_conv_block_form_matches_fp64(engines_bf16_chain_off_on, assets, B):
+    """The conv_block form of the chained launch (res2a: branch2c + projection shortcut branch1 as one GEMM over [t2 | block input] with
+    the BN scales folded into the bf16 weights, add, ReLU, then res2b_branch2a + ReLU) against the fp64 evaluation of the same rounded
+    operands -- weights folded in double and rounded once, exactly as hpe_finalize packs them (hpe_api.hip, GEMM_DUAL)."""
+    off, on = engines_bf16_chain_off_on
+    idx = resnet_spec.CONV_INDEX["res2a_branch2c"]
+    s, s1, sn = resnet_spec.CONV_SPECS[idx], resnet_spec.CONV_SPECS[idx + 1], resnet_spec.CONV_SPECS[idx + 2]
+    assert s1.name == "res2a_branch1" and sn.name == "res2b_branch2a"
+    g = np.random.Generator(np.random.Philox(2300 + B))
+    t2 = np.maximum(g.normal(0, 1, (B, 56, 56, s.cin)), 0).astype(np.float32)
+    x = np.maximum(g.normal(0, 2, (B, 56, 56, s1.cin)), 0).astype(np.float32)
+    t2[0, 0, 0, :] = 20.0
+    t3, u1, occ = on.debug_chain(idx, gpu(t2), gpu(x))
+    t3, u1 = cpu(t3), cpu(u1)
+    p = assets["enc"]
+    sc2, sh2 = _bn_fold(p, s)
+    sc1, sh1 = _bn_fold(p, s1)
+    w2 = _bf16_round((p[s.name + "/kernel"].astype(np.float64) * sc2).astype(np.float32))
+    w1 = _bf16_round((p[s1.name + "/kernel"].astype(np.float64) * sc1).astype(np.float32))
+    shift = (p[s.name + "/bias"].astype(np.float64) * sc2 + sh2) + (p[s1.name + "/bias"].astype(np.float64) * sc1 + sh1)
+    lin = (O.conv2d_nhwc(_bf16_round(t2), w2, None, 1, 0, dtype=np.float64) + O.conv2d_nhwc(_bf16_round(x), w1, None, 1, 0, dtype=np.float64)
+           + shift.astype(np.float32).astype(np.float64))
+    ref3 = np.maximum(lin, 0)
+    ulp = 2.0 ** -8
+    assert rel(t3, ref3) < ulp, rel(t3, ref3)
+    scn, shn = _bn_fold(p, sn)
     lin = O.conv2d_nhwc(_bf16_round(ref3), _bf16_round(p[sn.name + "/kernel"]), p[sn.name + "/bias"], 1, 0, dtype=np.float64) * scn + shn
     ref1 = np.maximum(lin, 0)
     assert rel(u1, ref1) < 2 * ulp, rel(u1, ref1)
