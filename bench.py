@@ -592,8 +592,28 @@ def _rel_rms(a, b):  # the tensor's own scale: max error over its RMS (small-mag
     return float(np.abs(a - b).max() / (np.sqrt(np.mean(np.square(b.astype(np.float64)))) + 1e-30))
 
 
-def parity_block(outs_last, ref, n, dtype="fp32", gate_kp2d_rms=False):
-    """Last-stage outputs of the first n images of a batch against the oracle's result dict `ref` (same images / weights)."""
+_KP2D_COND = {}
+
+
+def kp2d_conditioning(O, images_np, assets, reg, ref, n=8):
+    """Conditioning term of the own-scale kp2d error on the SURVEY regressor: the distance of the fp32 oracle from its own fp64 evaluation,
+    rel_rms(kp2d_oracle32, kp2d_oracle64), on the first n images (kp2d = s (x + t) with the camera scale cancelled to s ~ -0.03 amplifies
+    every rounding of theta; tests/test_gpu_parity.py::test_full_path_matches_oracle uses the same rule).  Cached per regressor."""
+    import numpy as np
+
+    key = id(reg)
+    if key not in _KP2D_COND:
+        n = min(n, images_np.shape[0], ref["generated_kp2d"].shape[0])
+        r64 = O.predict(images_np[:n].astype(np.float64), assets["enc"], reg, O.SMPL(assets["smpl"], dtype=np.float64),
+                        O.load_mean_param(assets["mean"], dtype=np.float64), dtype=np.float64)
+        _KP2D_COND[key] = _rel_rms(ref["generated_kp2d"][:n], r64["generated_kp2d"])
+    return _KP2D_COND[key]
+
+
+def parity_block(outs_last, ref, n, dtype="fp32", gate_kp2d_rms=False, kp2d_cond=None):
+    """Last-stage outputs of the first n images of a batch against the oracle's result dict `ref` (same images / weights).
+    kp2d own-scale error: fixed 1e-4 bar on the bounded regressor (gate_kp2d_rms); on the survey regressor the bar is
+    max(1e-4, 4 x kp2d_cond) with kp2d_cond = the oracle's own fp32-vs-fp64 distance (kp2d_conditioning) -- nothing printed is ungated."""
     import numpy as np
 
     j = outs_last["joints"][:n].cpu().numpy()
@@ -620,6 +640,12 @@ def parity_block(outs_last, ref, n, dtype="fp32", gate_kp2d_rms=False):
             "; kp2d_rel_rms is reported, not gated, on the survey regressor (its camera scale cancels to s ~ -0.03: kp2d = s (x + t) is ill-conditioned there)")
         par["worst_gated"] = max(par[k] for k in gated)
         par["pass"] = bool(par["worst_gated"] <= PARITY_BAR)
+        if not gate_kp2d_rms and kp2d_cond is not None and "kp2d_rel_rms" in par:
+            par["kp2d_conditioning"] = kp2d_cond
+            par["kp2d_bar"] = max(PARITY_BAR, 4.0 * kp2d_cond)
+            par["bar"] = par["bar"].replace("kp2d_rel_rms is reported, not gated, on the survey regressor",
+                                            "kp2d_rel_rms on the survey regressor is gated at kp2d_bar = max(1e-4, 4 x kp2d_conditioning), the oracle's own fp32-vs-fp64 distance")
+            par["pass"] = bool(par["pass"] and par["kp2d_rel_rms"] <= par["kp2d_bar"])
     else:
         l2 = float(np.linalg.norm(v.astype(np.float64) - ref["generated_verts"][:n]) / np.linalg.norm(ref["generated_verts"][:n]))
         par["verts_rel_l2"] = l2
@@ -809,7 +835,10 @@ def main():
             "batch1": {"images_per_sec": round(1.0 / t1, 3), "median_ms": round(t1 * 1e3, 2)},
             "batch%d" % n: {"images_per_sec": round(n / tn, 3), "median_ms": round(tn * 1e3, 2)},
         }
-        parity = parity_block(leg.last_outputs()[-1], ref, n, dtype=args.encoder_dtype, gate_kp2d_rms=(reg_variant == "bounded"))
+        cond = None
+        if args.encoder_dtype == "fp32" and reg_variant != "bounded":
+            cond = kp2d_conditioning(O, images.cpu().numpy(), assets, leg.reg, ref)
+        parity = parity_block(leg.last_outputs()[-1], ref, n, dtype=args.encoder_dtype, gate_kp2d_rms=(reg_variant == "bounded"), kp2d_cond=cond)
 
     # ---- the other single-GPU configurations of BASELINE.json, short legs in the same run (N == 1, default flags only)
     configs = None
@@ -843,7 +872,10 @@ def main():
                    "images_per_sec": round(lg.B * K / dt_, 2), "dtype": "f32" if lg.dtype == "fp32" else "bf16 encoder, fp32 accumulate / regressor / SMPL",
                    "host_us_per_step": round(lg.host_s / K * 1e6, 1), "roofline": roof, "phase_ms": ph}
             if ref_ is not None:
-                blk["parity"] = parity_block(lg.last_outputs()[-1], ref_, n_par, dtype=lg.dtype, gate_kp2d_rms=gate_kp2d)
+                cond_ = None
+                if lg.dtype == "fp32" and not gate_kp2d:
+                    cond_ = kp2d_conditioning(O, images.cpu().numpy(), assets, lg.reg, ref_)
+                blk["parity"] = parity_block(lg.last_outputs()[-1], ref_, n_par, dtype=lg.dtype, gate_kp2d_rms=gate_kp2d, kp2d_cond=cond_)
             return blk
 
         def fp32_b64():
@@ -899,7 +931,8 @@ def main():
                 out["eager_overlap_step" if m == "overlap" else "graph_replay"] = {
                     "ms_per_step": round(dt_ / K * 1e3, 4), "host_us_per_step": round(lg.host_s / K * 1e6, 1), "images_per_sec": round(B * K / dt_, 2)}
                 if m == "graph" and ref is not None:
-                    out["parity_graph"] = parity_block(lg.last_outputs()[-1], ref, min(64, args.cpu_sample))
+                    out["parity_graph"] = parity_block(lg.last_outputs()[-1], ref, min(64, args.cpu_sample),
+                                                       kp2d_cond=kp2d_conditioning(O, images.cpu().numpy(), assets, lg.reg, ref))
             return out
 
         def from_host_leg(pred4):

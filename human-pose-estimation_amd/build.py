@@ -37,8 +37,22 @@ def _obj_stale(src, obj):
     return any(os.path.getmtime(d) > t for d in [src] + _deps() if os.path.exists(d))
 
 
+def _flags_now():
+    return " ".join(CFLAGS + os.environ.get("HPE_EXTRA_FLAGS", "").split())
+
+
+def built_flags():
+    """compile flags of the library on disk ('' if unknown): lets tools that need a diagnostics build (-DHPE_ABLATION) check for it"""
+    tag = os.path.join(LIBDIR, "obj", "flags.txt")
+    return open(tag).read() if os.path.exists(tag) else ""
+
+
 def _stale():
     if not os.path.exists(LIB):
+        return True
+    # a library built with other flags (HPE_EXTRA_FLAGS, e.g. -DHPE_ABLATION) is stale whatever its age: without this check an
+    # ablation run silently measured the production build, and an ablation build stayed loaded for later production runs
+    if built_flags() != _flags_now():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hpe.h")]
@@ -55,7 +69,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     extra = os.environ.get("HPE_EXTRA_FLAGS", "").split()
     tag = os.path.join(objdir, "flags.txt")
-    flags_now = " ".join(CFLAGS + extra)
+    flags_now = _flags_now()
     if force or not os.path.exists(tag) or open(tag).read() != flags_now:
         for f in os.listdir(objdir):
             os.remove(os.path.join(objdir, f))

@@ -688,7 +688,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
     };
 
     issue_dma(ks0, 0);
-    __syncthreads();  // emits s_waitcnt vmcnt(0) before the barrier: the DMA has landed for every wave
+    // The wait for the LDS-DMA is WRITTEN OUT in front of every barrier that publishes DMA'd data (here and at the end of the loop body):
+    // __syncthreads() alone is a workgroup fence + s_barrier, and whether hipcc adds a vmcnt wait to it depends on the control flow around
+    // the DMA issue (round 3: conv_wino4.hip got lgkmcnt only and raced).  tools/isa_lint.py / tests/test_isa_lint.py check the ISA.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
 
     for (int s = ks0; s < ks1; ++s) {
         const int cur = ((s - ks0) & 1) * BUF;
@@ -712,6 +716,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of slab s + 1 has landed (see above)
         __syncthreads();
     }
 

@@ -171,7 +171,10 @@ __device__ __forceinline__ void wino_mainloop(const WinoArgs& p, float* lds, int
                 for (int j = 0; j < 2; ++j)
                     acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][i][ks], fb[0][j][ks], acc[0][i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();  // lgkmcnt(0): my fragments of slab s are in registers; vmcnt(0): my part of slab s+1 has landed
+        // my part of slab s+1 has landed: written out, not left to __syncthreads() (which guarantees lgkmcnt(0) -- my fragments of slab s
+        // are in registers -- but adds a vmcnt wait only behind some DMA patterns; tools/isa_lint.py checks the ISA)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
         if (s + 2 < n) issue(s + 2, s & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -546,7 +549,8 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(WinoFusedArgs p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     transform(0, 0);
-    __syncthreads();  // V(0) written by every wave; raw(1), U(0) landed
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), written out (see wino_gemm_loop): raw(1), U(0) landed
+    __syncthreads();                     // ... and V(0) written by every wave
     for (int s = 0; s < S; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
         if (s + 1 < S) issue_u(s + 1, nxt);
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(WinoFusedArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][i][ks], fb[1][j][ks], acc[1][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), written out: U(s + 1) and raw(s + 2) of this wave have landed
         __syncthreads();
     }
 

@@ -1551,7 +1551,12 @@ int hpe_preprocess_u8_batch(const unsigned char* frames, const long long* offset
         tab[b].offset = offsets[b];
     }
     // pageable source: the runtime stages the bytes before it returns, so `tab` may die at the end of this call
-    HIP_TRY(hipMemcpyAsync(table_dev, tab.data(), tab.size() * sizeof(PreprocFrame), hipMemcpyHostToDevice, st));
+    // The table lives on this call's stack: the copy must have READ it before the call returns.  hipMemcpyAsync from pageable memory
+    // happens to stage the bytes before returning on this runtime, but that is not a contract of the API -- so: wait for the work already
+    // on `st` (the scratch may still be read by an earlier launch), then a synchronous copy.  This path (frames of different sizes) is
+    // host-blocking and cannot be captured; the uniform-size path above needs no table at all.
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(table_dev, tab.data(), tab.size() * sizeof(PreprocFrame), hipMemcpyHostToDevice));
     HIP_TRY(hpe_launch_preprocess_u8_batch(frames, static_cast<const PreprocFrame*>(table_dev), PreprocFrame{}, B, C, HPE_IMG_SIZE / 2, out,
                                            HPE_IMG_SIZE, st));
     return HPE_OK;

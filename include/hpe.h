@@ -211,8 +211,8 @@ int hpe_preprocess_u8(const unsigned char* img_dev, int H, int W, int C, float* 
 /* The same for a batch of frames in ONE launch.  frames_dev: uint8 frames in one device buffer; frame i starts at byte
  * offsets[i] and is [sizes_hw[2i], sizes_hw[2i+1], C].  offsets == NULL: B frames of one size sizes_hw[0] x sizes_hw[1], back to
  * back (a camera / video stream) -- then no per-image table is needed and table_dev may be NULL.  Otherwise table_dev is a
- * caller-owned device scratch of >= 32 * B bytes; the per-image table is copied into it from pageable host memory on
- * `stream` (not capturable).  out_dev [B,224,224,3] float, proc_params (host, out) [B][5] as hpe_preprocess_u8. */
+ * caller-owned device scratch of >= 32 * B bytes; the per-image table is copied into it with a SYNCHRONOUS copy after
+ * `stream` has drained (this variant blocks the host and cannot be captured; equal-sized frames never take it).  out_dev [B,224,224,3] float, proc_params (host, out) [B][5] as hpe_preprocess_u8. */
 int hpe_preprocess_u8_batch(const unsigned char* frames_dev, const long long* offsets, const int* sizes_hw, int B, int C,
                             float* out_dev, int* proc_params, void* table_dev, void* stream);
 /* get_original (src/util/renderer.py:260-283): vert_shifted_dev [B,P,3] = verts + [tx, ty, 500 / (0.5*img_size*s)];
