@@ -206,27 +206,76 @@ def parse_cpulist(text):
     return cpus
 
 
+def cpu_share(cpus, n_sharing, index):
+    """The index-th of n_sharing contiguous, disjoint, near-equal parts of a sorted CPU list (the first len % n parts get one more)."""
+    cpus = sorted(cpus)
+    n_sharing = max(1, n_sharing)
+    q, r = divmod(len(cpus), n_sharing)
+    lo = index * q + min(index, r)
+    return cpus[lo:lo + q + (1 if index < r else 0)]
+
+
+def plan_rank_cpus(node_of_rank, node_cpus, local_rank):
+    """CPUs of one local rank: the cores of its GPU's NUMA node, split between the local ranks whose GPUs sit on the same node --
+    disjoint sets over the ranks of a host (8 ranks on a 128-core two-node host: 16 cores each).  node_of_rank[r] = NUMA node of local
+    rank r's GPU (-1 / missing: unknown -> None: no pinning), node_cpus[node] = usable cores of that node."""
+    node = node_of_rank[local_rank]
+    if node is None or node < 0 or not node_cpus.get(node):
+        return None
+    sharing = [r for r, nd in enumerate(node_of_rank) if nd == node]
+    part = cpu_share(node_cpus[node], len(sharing), sharing.index(local_rank))
+    return part or None
+
+
+def _gpu_numa_node(torch, idx):
+    p = torch.cuda.get_device_properties(idx)
+    bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+        return bdf, int(f.read().strip())
+
+
 def pin_rank_to_gpu_numa(torch, local_rank, world):
-    """Pin this rank to the cores of its GPU's NUMA node (sysfs `numa_node` of the PCI device) and split those cores between
-    the ranks that share the node; cap the CPU thread pools accordingly.  Best effort: returns a description or None."""
+    """Pin this rank to its share of the cores of its GPU's NUMA node (sysfs `numa_node` of the PCI device; the node's cores are split
+    between the local ranks on that node, disjoint sets) and cap the CPU thread pools at that share.  Best effort: returns a
+    description or None."""
     try:
-        p = torch.cuda.get_device_properties(local_rank)
-        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
-        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
-            node = int(f.read().strip())
+        bdf, node = _gpu_numa_node(torch, local_rank)
         if node < 0:
             return None
+        n_local = min(world, torch.cuda.device_count())
+        node_of_rank = []
+        for r in range(n_local):
+            try:
+                node_of_rank.append(_gpu_numa_node(torch, r)[1])
+            except Exception:  # noqa: BLE001
+                node_of_rank.append(-1)
         with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
-            cpus = sorted(set(parse_cpulist(f.read())) & set(os.sched_getaffinity(0)))
+            usable = sorted(set(parse_cpulist(f.read())) & set(os.sched_getaffinity(0)))
+        cpus = plan_rank_cpus(node_of_rank, {node: usable}, local_rank) if local_rank < n_local else None
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
-        nthreads = max(1, min(len(cpus), (os.cpu_count() or len(cpus)) // max(world, 1)))
+        nthreads = max(1, len(cpus))
         torch.set_num_threads(nthreads)
-        return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "torch_threads": nthreads}
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "first_cpu": cpus[0], "torch_threads": nthreads}
     except Exception as e:  # noqa: BLE001 -- placement is an optimisation, never a reason to fail the run
         print("bench.py: NUMA pinning skipped (%s)" % e, file=sys.stderr)
         return None
+
+
+# ------------------------------------------------------------------------------------------------- N > 1: the line verifies itself
+def reduce_dist_check(torch, dist, world, gather_ok, parity_pass, worst_gated, device):
+    """Every rank contributes (its gathered slice equals its own theta, its parity block passed, its worst gated error); ONE MIN
+    all-reduce makes the verdict identical on every rank, so that every rank exits 3 when any rank failed (tests/test_distributed_gloo.py
+    runs this over gloo with 8 ranks and one of them forced to fail)."""
+    flags = torch.tensor([1.0 if gather_ok else 0.0, 1.0 if parity_pass else 0.0, -float(worst_gated)], dtype=torch.float64, device=device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    return {"ranks": world, "gather_slice_equals_local_theta_on_every_rank": bool(flags[0].item() > 0.5),
+            "parity_pass_on_every_rank": bool(flags[1].item() > 0.5), "worst_gated_over_ranks": float(-flags[2].item())}
+
+
+def dist_check_failed(dist_check):
+    return not (dist_check["gather_slice_equals_local_theta_on_every_rank"] and dist_check["parity_pass_on_every_rank"])
 
 
 # ------------------------------------------------------------------------------------------------- power / clock sampling
@@ -792,12 +841,9 @@ def main():
         mean = O.load_mean_param(assets["mean"])
         ref2 = O.predict(images[:n_chk].cpu().numpy(), assets["enc"], leg.reg, osmpl, mean)
         p2 = parity_block(leg.last_outputs()[-1], ref2, n_chk, dtype=args.encoder_dtype, gate_kp2d_rms=(reg_variant == "bounded"))
-        flags = torch.tensor([1.0 if gather_ok else 0.0, 1.0 if p2["pass"] else 0.0, -p2["worst_gated"]], dtype=torch.float64, device="cuda")
-        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-        dist_check = {"ranks": world, "gather_slice_equals_local_theta_on_every_rank": bool(flags[0].item() > 0.5),
-                      "parity_pass_on_every_rank": bool(flags[1].item() > 0.5), "worst_gated_over_ranks": float(-flags[2].item()),
-                      "images_checked_per_rank": n_chk, "rank0": {k: p2[k] for k in p2 if k.endswith("_rel_err") or k.endswith("_rel_rms")},
-                      "placement_rank0": placement}
+        dist_check = reduce_dist_check(torch, dist, world, gather_ok, p2["pass"], p2["worst_gated"], "cuda")
+        dist_check.update({"images_checked_per_rank": n_chk, "rank0": {k: p2[k] for k in p2 if k.endswith("_rel_err") or k.endswith("_rel_rms")},
+                           "placement_rank0": placement})
 
     cpu_baseline = None
     parity = None
@@ -1026,7 +1072,7 @@ def main():
     failed = []
     if parity is not None and not parity["pass"]:
         failed.append("headline parity: worst gated relative error %.3g" % parity["worst_gated"])
-    if dist_check is not None and not (dist_check["gather_slice_equals_local_theta_on_every_rank"] and dist_check["parity_pass_on_every_rank"]):
+    if dist_check is not None and dist_check_failed(dist_check):
         failed.append("dist_check: %s" % json.dumps({k: v for k, v in dist_check.items() if k != "rank0"}))
     for name, blk in list((configs or {}).items()) + list(extras.items()):
         for key in ("parity", "loss_parity", "parity_graph"):

@@ -8,21 +8,27 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_launcher_propagates_rank_failure():
+import pytest
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_launcher_propagates_rank_failure(n):
+    """n = 8 is the driver's scaling run: eight rank processes, the node's assets written once into /dev/shm by the parent and removed
+    again, the first failing rank's code relayed, no JSON line."""
     import torch
 
     if torch.cuda.is_available():
-        import pytest
-
         pytest.skip("needs a box without a GPU (the GPU-box counterpart is tests/test_gpu_dist.py)")
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
-                        "--cpu-sample", "0", "--sustain", "0"], env=env, capture_output=True, text=True, timeout=600)
+    before = set(f for f in os.listdir("/dev/shm") if f.startswith("hpe_bench_assets"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--batch", "8",
+                        "--cpu-sample", "0", "--sustain", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "rank" in r.stderr and "exited with code" in r.stderr
+    assert set(f for f in os.listdir("/dev/shm") if f.startswith("hpe_bench_assets")) == before  # the parent cleaned up
 
 
 def test_launcher_is_bypassed_under_a_launcher_env():
