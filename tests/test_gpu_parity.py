@@ -294,6 +294,76 @@ def test_winograd4_fused_conv_matches_oracle(assets, name, B):
     e.close()
 
 
+def _stress_encoder_params(enc, seed, normalise):
+    """The synthetic encoder with HEAVY-TAILED BatchNorm scales: gamma log-uniform in [0.05, 10] per channel (a trained network's
+    dynamic range; the default draw has gamma in [0.5, 1.5]).  normalise: divide by the RMS of that law (3.07) so that a whole
+    53-layer network keeps finite activations -- the per-channel spread (200x) is what stresses the Winograd transforms, not the mean."""
+    g = np.random.Generator(np.random.Philox(seed))
+    out = dict(enc)
+    for k in enc:
+        if k.endswith("/gamma"):
+            gam = np.exp(g.uniform(np.log(0.05), np.log(10.0), enc[k].shape))
+            out[k] = (gam / 3.07 if normalise else gam).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("name", ["res3b_branch2b", "res4c_branch2b", "res5b_branch2b"])
+def test_winograd4_dynamic_range_stress_layer(assets, name):
+    """F(4x4,3x3) vs the direct kernel vs the fp64 convolution on a trained-network dynamic range: activations with magnitudes from 1e-3
+    to 1e2 mixed inside every 6x6 tile (|N(0,1)| x 10^U(-3,2), 30 % exact zeros) and BatchNorm scales log-uniform in [0.05, 10].  The
+    bars are the FROZEN ones of test_winograd4_conv_matches_oracle (max error <= 5e-5 of the layer's largest output, rel-L2 <= 2e-5);
+    the measured factor F(4x4) / direct is printed.  The error of a Winograd tile scales with the largest input of the TILE, so against
+    the layer's largest output heavy tails make the relative error smaller, not larger -- what could break is a per-channel scale of
+    10 on a channel of small outputs, which the own-scale check per output channel (max error / that channel's RMS) covers."""
+    enc = _stress_encoder_params(assets["enc"], 7700, normalise=False)
+    a2 = dict(assets, enc=enc)
+    f4 = encoder_engine(a2, 8, wino_f4=15, wino_min_items=0)
+    direct = encoder_engine(a2, 8, wino_min_c=0)
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    g = np.random.Generator(np.random.Philox(7800 + idx))
+    B = 2
+    x = (np.abs(g.normal(0, 1, (B, s.hin, s.hin, s.cin))) * 10.0 ** g.uniform(-3, 2, (B, s.hin, s.hin, s.cin))).astype(np.float32)
+    x[g.random(x.shape) < 0.3] = 0.0
+    yw = cpu(f4.debug_conv(idx, gpu(x), relu=False)).astype(np.float64)
+    yd = cpu(direct.debug_conv(idx, gpu(x), relu=False)).astype(np.float64)
+    sc, sh = _bn_fold(enc, s)
+    ref = O.conv2d_nhwc(x, enc[s.name + "/kernel"], enc[s.name + "/bias"], 1, 1, dtype=np.float64) * sc + sh
+    ew, ed = rel(yw, ref), rel(yd, ref)
+    l2w = float(np.linalg.norm(yw - ref) / np.linalg.norm(ref))
+    ch_rms = np.sqrt(np.mean(ref ** 2, axis=(0, 1, 2)))
+    own_w = float((np.abs(yw - ref).max(axis=(0, 1, 2)) / ch_rms).max())
+    own_d = float((np.abs(yd - ref).max(axis=(0, 1, 2)) / ch_rms).max())
+    print("stress %s: F(4x4) max rel %.3g rel-L2 %.3g worst channel own-scale %.3g | direct %.3g / %.3g | factor %.1fx (max), %.1fx (own scale)"
+          % (name, ew, l2w, own_w, ed, own_d, ew / max(ed, 1e-30), own_w / max(own_d, 1e-30)))
+    assert ew < 5e-5 and l2w < 2e-5, (ew, l2w)
+    assert ed < 5e-6, ed
+    assert own_w < 1e-3, own_w  # every output channel on ITS OWN scale (max error over the channel's RMS): still 10x inside 1e-4 x peak/RMS
+    f4.close()
+    direct.close()
+
+
+def test_winograd4_dynamic_range_stress_encoder(assets):
+    """The whole encoder with the heavy-tailed BatchNorm scales (normalised to unit RMS so 53 layers stay finite): features of the default
+    plan (F(4x4) on 13 layers), of all sixteen 3x3 layers as F(4x4) and of the all-direct plan against the fp64 oracle.  North star:
+    1e-4 on the path's outputs; the gate here is 2e-5 on the features, an order inside it."""
+    enc = _stress_encoder_params(assets["enc"], 7900, normalise=True)
+    a2 = dict(assets, enc=enc)
+    img = synthetic.make_images(2, seed=7901)
+    ref = O.resnet50_features(img.astype(np.float64), enc, dtype=np.float64)
+    assert np.isfinite(ref).all() and float(np.abs(ref).max()) > 0
+    errs = {}
+    for label, opts in (("default", {}), ("all F(4x4)", dict(wino_f4=15, wino_min_items=0)), ("direct", dict(wino_min_c=0))):
+        e = encoder_engine(a2, 8, **opts)
+        f = cpu(e.encoder(gpu(img))).astype(np.float64)
+        errs[label] = (rel(f, ref), float(np.linalg.norm(f - ref) / np.linalg.norm(ref)))
+        e.close()
+    print("stress encoder (gamma log-uniform [0.05, 10] / 3.07): " + "; ".join("%s max rel %.3g rel-L2 %.3g" % (k, v[0], v[1]) for k, v in errs.items())
+          + "; factor all-F(4x4) / direct %.1fx" % (errs["all F(4x4)"][0] / max(errs["direct"][0], 1e-30)))
+    for k, v in errs.items():
+        assert v[0] < 2e-5, (k, v)
+
+
 def test_winograd4_encoder_features(engine_wino4, engines_direct_and_wino, assets):
     """Whole encoder with all sixteen 3x3 layers as F(4x4,3x3): the per-layer error does not accumulate -- features stay within
     fp32 round-off of the all-direct context and of the oracle."""

@@ -53,8 +53,9 @@ def pmc_rows(db):
 
 
 def main():
-    kt, fdb, wdb = sys.argv[1:4]
-    mdb = sys.argv[4] if len(sys.argv) > 4 else None
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    kt, fdb, wdb = pos[:3]
+    mdb = pos[3] if len(pos) > 3 else None
     t = {}
     for name, s, e, _d in kernel_rows(kt):
         k = short(name)
@@ -85,7 +86,32 @@ def main():
         tot_t += ms
         tot_b += fb + wb
     print("\ntotal %.2f ms, %.2f GB" % (tot_t, tot_b / 1e9))
-    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("w4_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream")]
+    # ---- the conv family = the encoder's launches: everything dispatched before the global average pool of the pass (the regressor's
+    #      Dense layers run through conv_gemm_f32_dma_kernel too, after it).  The fraction is GENERATED here so that DESIGN.md quotes it.
+    rows = kernel_rows(kt)
+    pool = [i for i, r in enumerate(rows) if "avgpool" in r[0]]
+    enc_rows = rows[:pool[-1]] if pool else rows
+    enc_ms = sum((e - s0) / 1e6 for _n, s0, e, _d in enc_rows)
+    batch = 256
+    for a in sys.argv[1:]:
+        if a.startswith("--batch="):
+            batch = int(a.split("=", 1)[1])
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+    import hpe_amd.resnet_spec as rs
+
+    bf16 = any("bf16" in r[0] for r in enc_rows)
+    if enc_ms > 0:
+        if bf16:
+            gb = rs.encoder_min_bytes_per_image(2) * batch / 1e9
+            print("\nconv family (encoder launches before the average pool, profiler attached, chunk streams off): %d launches, %.3f ms; "
+                  "algorithmic %.2f GB (every conv output written and read once, bf16) -> %.2f TB/s = %.3f of 8 TB/s"
+                  % (len(enc_rows), enc_ms, gb, gb / enc_ms, gb / enc_ms / 8.0))
+        else:
+            gf = 2.0 * rs.encoder_macs_per_image() * batch / 1e9
+            print("\nconv family (encoder launches before the average pool, profiler attached, chunk streams off): %d launches, %.3f ms; "
+                  "algorithmic %.1f GFLOP (direct-convolution FLOPs) -> %.1f TFLOP/s = %.3f of 157.3 TFLOP/s"
+                  % (len(enc_rows), enc_ms, gf, gf / enc_ms, gf / enc_ms / 157.3))
+    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("w4_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream") or k.startswith("chain_")]
     cf = sum(fetch.get(k, 0.0) for k in conv)
     cw = sum(write.get(k, 0.0) for k in conv)
     print("\nJSON " + json.dumps({"fetch_bytes_corrected": cf, "write_bytes": cw, "total_bytes": cf + cw, "kernels": sorted(conv)}))
