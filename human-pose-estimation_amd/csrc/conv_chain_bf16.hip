@@ -49,6 +49,17 @@ namespace {
 __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// The same with the non-temporal cache policy (aux bit 1) for the residual, which is read exactly once; the t3 rows (4C wide, next read a
+// whole 3x3 layer later) are stored non-temporal too.  What that buys is cache room for the C-wide u1 rows, which the next launch (the
+// 3x3 layer) reads: A/B on one box (tools/chain_nt_ab.sh, -DHPE_CHAIN_NO_NT = plain policy): res2c_branch2b 0.109 -> 0.097 ms, the chained
+// launches themselves 0.200 -> 0.195 / 0.132 -> 0.129 ms, bf16 step 69.4-69.5 k -> 70.1-70.8 k img/s.
+__device__ __forceinline__ void dma16_nt(const void* src, void* lds_dst) {
+#ifndef HPE_CHAIN_NO_NT
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#endif
+}
 
 // Barriers are written out: __syncthreads() is a workgroup fence + s_barrier, and behind pending LDS-DMA hipcc puts a vmcnt(0) in
 // front of some of them (here: the one after the in-place epilogue, which would make waves 2-3 wait for the residual chunk they have
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
         for (int s = 0; s < KSB; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                dma16(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + (c % QBUFS) * QBYTES + s * SLAB + (wave + 4 * i) * 1024);
+                dma16_nt(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + (c % QBUFS) * QBYTES + s * SLAB + (wave + 4 * i) * 1024);
     };
     auto issue_wa = [&](int c) {  // W2c rows [c * NC, + NC), all KSA k-slabs -> slot A
 #pragma unroll
@@ -276,7 +287,11 @@ __global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainA
                 const int r = idx / UPR, u = idx - r * UPR;
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(Q + (u >> 3) * SLAB + r * 128 + (((u & 7) ^ ((r >> 1) & 7)) << 4));
                 const int m = m0 + r;
+#ifndef HPE_CHAIN_NO_NT
+                if (m < p.M) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.t3 + (size_t)m * C4 + c * NC + u * 8));
+#else
                 if (m < p.M) *reinterpret_cast<bf16x8*>(p.t3 + (size_t)m * C4 + c * NC + u * 8) = v;
+#endif
             }
         }
 #pragma unroll

@@ -755,18 +755,51 @@ __global__ __launch_bounds__(256) void sil_compact_bits_kernel(const unsigned lo
 // reference's expanded fp32 form and ties are resolved to the lowest (y, x) = lowest tf.where index, so the chosen pixel is
 // the one tf.argmin picks.  ~2*sqrt(d) rows x 2 candidates per vertex instead of P_i (~12k) candidates.
 #define NN_MAXWW 8
+// Round 4: two things cut the walk (0.29 -> see DESIGN.md ms per stage at B = 256), neither changes which pixel wins:
+//  * a per-row record built once per workgroup from the bitmap -- first and last set column and whether the row is ONE run of set
+//    pixels (a convex silhouette: every row) -- answers "nearest set bit at or left of x0 / right of x0" with two clamps instead of
+//    two word-by-word scans with 64-bit clz / ffs (rows with several runs keep the scans); empty rows cost one LDS read;
+//  * the walk starts at the vertex' row clamped into the silhouette's row range [ymin, ymax] and never leaves that range: the rows it
+//    skips are empty.  The visiting order does not matter: try_pixel's tie rule is explicit and a row is pruned only by its own
+//    vertical distance against the best value so far, which is monotone along each direction.
 __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
                                                           const float* __restrict__ v2d, int H, int W, int WW, int P,
                                                           float* __restrict__ partial, int nblk, int blk_off) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long sbits[];  // [H][WW]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sbits[];  // [H][WW], then rowinfo[H]
     __shared__ float red[4];
+    __shared__ int s_ymin, s_ymax;
+    unsigned* rowinfo = reinterpret_cast<unsigned*>(sbits + H * WW);  // xl | xr << 10 | kind << 20 (0 empty, 1 one run, 2 several runs)
     const int b = blockIdx.y;
     const int cnt = counts[b];
+    if (threadIdx.x == 0) {
+        s_ymin = H;
+        s_ymax = -1;
+    }
     for (int i = threadIdx.x; i < H * WW; i += 256) sbits[i] = bits[(size_t)b * H * WW + i];
     __syncthreads();
+    for (int y = threadIdx.x; y < H; y += 256) {
+        int xl = -1, xr = -1, pc = 0;
+        for (int i = 0; i < WW; ++i) {
+            const unsigned long long m = sbits[y * WW + i];
+            if (m) {
+                if (xl < 0) xl = i * 64 + __ffsll((long long)m) - 1;
+                xr = i * 64 + 63 - __clzll(m);
+                pc += __popcll(m);
+            }
+        }
+        unsigned info = 0;
+        if (pc > 0) {
+            info = (unsigned)xl | ((unsigned)xr << 10) | ((pc == xr - xl + 1 ? 1u : 2u) << 20);
+            atomicMin(&s_ymin, y);
+            atomicMax(&s_ymax, y);
+        }
+        rowinfo[y] = info;
+    }
+    __syncthreads();
+    const int ymin = s_ymin, ymax = s_ymax;
     const int p = blockIdx.x * 256 + threadIdx.x;
     float contrib = 0.f;
-    if (p < P && cnt > 0) {
+    if (p < P && cnt > 0 && ymax >= ymin) {
         const float bx = v2d[((size_t)b * P + p) * 2], by = v2d[((size_t)b * P + p) * 2 + 1];
         const float bb = bx * bx + by * by;
         const int x0 = min(max((int)rintf(bx), 0), W - 1);
@@ -783,6 +816,15 @@ __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long lo
             }
         };
         auto scan_row = [&](int y) {
+            const unsigned info = rowinfo[y];
+            const unsigned kind = info >> 20;
+            if (kind == 0) return;
+            if (kind == 1) {
+                const int xl = (int)(info & 1023u), xr = (int)((info >> 10) & 1023u);
+                if (xl <= x0) try_pixel(min(x0, xr), y);      // nearest set bit at or left of x0
+                if (xr > x0) try_pixel(max(x0 + 1, xl), y);   // nearest set bit right of x0
+                return;
+            }
             const unsigned long long* row = sbits + y * WW;
             // nearest set bit at or left of x0
             for (int i = x0 >> 6; i >= 0; --i) {
@@ -804,19 +846,22 @@ __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long lo
                 }
             }
         };
-        scan_row(y0);
+        const int ys = min(max(y0, ymin), ymax);
+        scan_row(ys);
         bool up = true, down = true;
         for (int k = 1; (up || down) && k < H; ++k) {
             if (down) {
-                const int y = y0 + k;
+                const int y = ys + k;
                 const float dy = (float)y - by;
-                if (y >= H || dy * dy > best + 0.25f) down = false;  // expanded-form rounding error is << 0.25 here
+                // rows below ymax are empty; a row farther than the best distance cannot win (expanded-form rounding error << 0.25;
+                // dy < 0 only while the walk is still above the vertex, i.e. the vertex lies below the silhouette: no pruning there)
+                if (y > ymax || (dy > 0.f && dy * dy > best + 0.25f)) down = false;
                 else scan_row(y);
             }
             if (up) {
-                const int y = y0 - k;
+                const int y = ys - k;
                 const float dy = by - (float)y;
-                if (y < 0 || dy * dy > best + 0.25f) up = false;
+                if (y < ymin || (dy > 0.f && dy * dy > best + 0.25f)) up = false;
                 else scan_row(y);
             }
         }
@@ -983,7 +1028,7 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
     if (e != hipSuccess) return e;
     if (ev_a2b1) (void)hipEventRecord(ev_a2b1, st);
     if (m.grid_path) {
-        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(m.nB, B), dim3(256), (size_t)H * m.WW * 8, st, m.bits, m.counts, v2d, H, W, m.WW, P,
+        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(m.nB, B), dim3(256), (size_t)H * m.WW * 8 + (size_t)H * 4, st, m.bits, m.counts, v2d, H, W, m.WW, P,
                            m.partial, m.nblk, m.nA);
     } else {
         hipLaunchKernelGGL(nn_b2a_kernel, dim3(m.nB, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk, m.nA);
