@@ -939,14 +939,16 @@ def main():
             finally:
                 lg.close()
 
-        def config5_b256():
-            lg = Leg(env, B, reg_variant="bounded", config5=True, images=images)
+        def config5_b256(variant="bounded"):
+            lg = Leg(env, B, reg_variant=variant, config5=True, images=images)
             try:
                 lg.eng.forward(images[:2], all_stages=True)
                 n5 = 2
                 ref5 = O.predict(images[:n5].cpu().numpy(), assets["enc"], lg.reg, osmpl, mean, all_stages=True)
+                desc = ("well-conditioned synthetic regressor ('bounded': camera scale 0.83 / 0.76 / 0.69, every stage on the cell-grid search)" if variant == "bounded" else
+                        "SURVEY regressor (camera scale 0.59 / 0.28 / -0.03: the meshes of stages 2-3 collapse into a few cells and take the full-search fallback)")
                 blk = leg_block(lg, K, "configs[4] on one GPU: batch=256/GPU LSP-shaped inputs, fp32 path + kp / mesh reprojection losses of all 3 stages "
-                                       "(one library call), well-conditioned synthetic regressor ('bounded': camera scale 0.83 / 0.76 / 0.69)", ref5, n5, gate_kp2d=True)
+                                       "(one library call), " + desc, ref5, n5, gate_kp2d=(variant == "bounded"))
                 blk["loss_roofline"] = loss_roofline_block(lg)
                 pk = lg.last_losses().cpu().numpy()
                 blk["losses_last_step"] = {"kpr": [float(60.0 * x) for x in pk[:, 2]], "mr": [float(0.001 * x) for x in pk[:, 3]]}
@@ -1001,6 +1003,7 @@ def main():
         leg.close()
         configs["bf16_b256"] = run_leg("bf16_b256", bf16_b256)
         configs["config5_b256"] = run_leg("config5_b256", config5_b256)
+        configs["config5_b256_survey"] = run_leg("config5_b256_survey", lambda: config5_b256("survey"))
         try:
             lg4 = Leg(env, B, images=images)  # a fresh fp32 context for the two legs that bring their own streams
             lg4.eng.forward(images[:2], all_stages=True)
@@ -1063,6 +1066,16 @@ def main():
         if configs:
             line["configs"] = configs
         line.update(extras)
+        if configs:
+            # the LAST key of the line: the figures of every leg in one short block (a log tail that keeps only the end of the line keeps this)
+            def _ips(blk):
+                return blk.get("images_per_sec") if isinstance(blk, dict) else None
+
+            line["summary_images_per_sec"] = {"fp32_b256_headline": round(value, 1), **{k: _ips(v) for k, v in configs.items()},
+                                              "from_host": _ips(extras.get("from_host")),
+                                              "graph_replay": (extras.get("graph") or {}).get("graph_replay", {}).get("images_per_sec"),
+                                              "bf16_b256_frac_of_8TBs": ((configs.get("bf16_b256") or {}).get("roofline") or {}).get("frac"),
+                                              "fp32_b256_frac_of_157TF": (roofline or {}).get("frac")}
         # stdout carries exactly one line: native libraries (RCCL prints a version banner on fd 1 when its communicator is
         # created) wrote to stderr for the whole run, the JSON goes to the real stdout
         sys.stdout.flush()

@@ -823,9 +823,16 @@ hipError_t launch_cfg(GemmArgs& p, hipStream_t st) {
     if ((stage_variant() == 1 && p.zero) || MODE == GEMM_DUAL) {
         // latency-bound small grids: cut K so that about one workgroup per CU runs (>= 4 slabs per slice)
         const int S = p.K / BK;
-        if (p.partial && splitk_enabled() && grid < 128 && S >= 8) {
+        // slabs per slice: >= 4 (HPE_SPLITK_SLABS; a slice shorter than that is all launch ramp).  Every split layer pays a second,
+        // dependent launch (the fix-up), which costs a single frame about what 6-8 more slabs in the main loop cost.
+        static const int min_slabs = [] {
+            const char* e = getenv("HPE_SPLITK_SLABS");
+            const int v = e ? atoi(e) : 4;
+            return v < 2 ? 2 : v;
+        }();
+        if (p.partial && splitk_enabled() && grid < 128 && S >= 2 * min_slabs) {
             int sk = 256 / grid;
-            if (sk > S / 4) sk = S / 4;
+            if (sk > S / min_slabs) sk = S / min_slabs;
             if (sk > 16) sk = 16;
             while (sk > 1 && (size_t)grid * sk * BM * BN > p.partial_floats) --sk;
             if (sk > 1) p.split_k = sk;
