@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, 3) void nn_a2b_mfma_kernel(const float* __rest
             }
         }
     }
-    if (mfma_count && lane == 0) atomicAdd(mfma_count, (unsigned long long)(((P + 31) >> 5) * NN_PG));
+    // diagnostics counter: one atomic per workgroup (its four waves issue the same number of MFMAs)
+    if (mfma_count && threadIdx.x == 0) atomicAdd(mfma_count, (unsigned long long)(((P + 31) >> 5) * NN_PG) * 4ull);
     float contrib = 0.f;
 #pragma unroll
     for (int g = 0; g < NN_PG; ++g) {
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         if (lane == 0) v = atomicAdd(&s_next, 1);
         return __shfl(v, 0, 64);
     };
+    int wave_mfma = 0;  // MFMAs issued by this wave (diagnostics)
     auto tile_sum = [&](int q) -> float {
         const int tile = q * nslice + slice;
         const int ty = tile / TX, tx = tile - ty * TX;
@@ -611,13 +613,17 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off, 64);
-        if (mfma_count && lane == 0) atomicAdd(mfma_count, (unsigned long long)(nchunk * NPG));
+        wave_mfma += nchunk * NPG;
         return contrib;
     };
     for (int q = next_tile(); q < nq; q = next_tile()) {
         const float c = tile_sum(q);
         if (lane == 0) sTile[q] = c;
     }
+    // diagnostics counter: ONE atomic per wave.  (Round 3 added one per TILE: ~200 k atomics on one address per launch, which serialise
+    // at ~88 per microsecond -- the counted step of bench.py's loss_roofline measured 0.77 ms per search where the uncounted kernel takes
+    // 0.35 ms, so `frac` was 2x pessimistic.)
+    if (mfma_count && lane == 0 && wave_mfma) atomicAdd(mfma_count, (unsigned long long)wave_mfma);
     __syncthreads();
     float acc = 0.f;
     for (int q = t; q < nq; q += 1024) acc += sTile[q];
@@ -761,7 +767,12 @@ __global__ __launch_bounds__(256) void sil_compact_bits_kernel(const unsigned lo
 //    two word-by-word scans with 64-bit clz / ffs (rows with several runs keep the scans); empty rows cost one LDS read;
 //  * the walk starts at the vertex' row clamped into the silhouette's row range [ymin, ymax] and never leaves that range: the rows it
 //    skips are empty.  The visiting order does not matter: try_pixel's tie rule is explicit and a row is pruned only by its own
-//    vertical distance against the best value so far, which is monotone along each direction.
+//    vertical distance against the best value so far, which is monotone along each direction;
+//  * rows are visited in aligned blocks of 8 with a record per block (smallest first column, largest last column): a block whose
+//    bounding rectangle is farther from the vertex than the best distance so far is skipped whole.  A vertex beside the silhouette
+//    used to scan every row within its horizontal distance; the rows above and below where the shape has narrowed away from it now
+//    cost one rectangle test per 8.  (The rectangle bound is not monotone along the walk -- a farther block may be wider -- so only
+//    the vertical distance ends a direction.)
 __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ counts,
                                                           const float* __restrict__ v2d, int H, int W, int WW, int P,
                                                           float* __restrict__ partial, int nblk, int blk_off) {
@@ -769,6 +780,7 @@ __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long lo
     __shared__ float red[4];
     __shared__ int s_ymin, s_ymax;
     unsigned* rowinfo = reinterpret_cast<unsigned*>(sbits + H * WW);  // xl | xr << 10 | kind << 20 (0 empty, 1 one run, 2 several runs)
+    unsigned* blkinfo = rowinfo + H;                                  // per aligned block of 8 rows: min xl | max xr << 10 | nonempty << 20
     const int b = blockIdx.y;
     const int cnt = counts[b];
     if (threadIdx.x == 0) {
@@ -794,6 +806,19 @@ __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long lo
             atomicMax(&s_ymax, y);
         }
         rowinfo[y] = info;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < (H + 7) / 8; j += 256) {
+        unsigned lo = 1023u, hi_ = 0u, any = 0u;
+        for (int y = 8 * j; y < min(8 * j + 8, H); ++y) {
+            const unsigned info = rowinfo[y];
+            if (info >> 20) {
+                lo = min(lo, info & 1023u);
+                hi_ = max(hi_, (info >> 10) & 1023u);
+                any = 1u;
+            }
+        }
+        blkinfo[j] = lo | (hi_ << 10) | (any << 20);
     }
     __syncthreads();
     const int ymin = s_ymin, ymax = s_ymax;
@@ -848,21 +873,58 @@ __global__ __launch_bounds__(256) void nn_b2a_rows_kernel(const unsigned long lo
         };
         const int ys = min(max(y0, ymin), ymax);
         scan_row(ys);
-        bool up = true, down = true;
-        for (int k = 1; (up || down) && k < H; ++k) {
+        int yd = ys + 1, yu = ys - 1;
+        bool down = yd <= ymax, up = yu >= ymin;
+        // squared distance from the vertex to the block's bounding rectangle [min xl, max xr] x [rows of the segment]; dyv = vertical
+        // distance to the segment's nearest row (<= 0: the vertex is level with or inside the segment's rows)
+        auto block_far = [&](unsigned binfo, float dyv) {
+            if (!(binfo >> 20)) return true;
+            const float xl = (float)(binfo & 1023u), xr = (float)((binfo >> 10) & 1023u);
+            const float dxr = fmaxf(fmaxf(xl - bx, bx - xr), 0.f), dyr = fmaxf(dyv, 0.f);
+            return dxr * dxr + dyr * dyr > best + 0.5f;  // the expanded-form rounding error of a candidate is << 0.5 at these magnitudes
+        };
+        while (down || up) {
             if (down) {
-                const int y = ys + k;
-                const float dy = (float)y - by;
-                // rows below ymax are empty; a row farther than the best distance cannot win (expanded-form rounding error << 0.25;
-                // dy < 0 only while the walk is still above the vertex, i.e. the vertex lies below the silhouette: no pruning there)
-                if (y > ymax || (dy > 0.f && dy * dy > best + 0.25f)) down = false;
-                else scan_row(y);
+                // rows yd .. yend: the rest of yd's aligned block of 8.  A row farther than the best distance cannot win (and neither can
+                // any row below it): the direction ends; dy <= 0 only while the walk is still above the vertex (no pruning there).
+                const int yend = min((yd | 7), ymax);
+                const float dy0 = (float)yd - by;
+                if (dy0 > 0.f && dy0 * dy0 > best + 0.25f) {
+                    down = false;
+                } else {
+                    if (!block_far(blkinfo[yd >> 3], dy0)) {
+                        for (int y = yd; y <= yend; ++y) {
+                            const float dy = (float)y - by;
+                            if (dy > 0.f && dy * dy > best + 0.25f) {
+                                down = false;
+                                break;
+                            }
+                            scan_row(y);
+                        }
+                    }
+                    yd = yend + 1;
+                    if (yd > ymax) down = false;
+                }
             }
             if (up) {
-                const int y = ys - k;
-                const float dy = by - (float)y;
-                if (y < ymin || (dy > 0.f && dy * dy > best + 0.25f)) up = false;
-                else scan_row(y);
+                const int yend = max((yu & ~7), ymin);
+                const float dy0 = by - (float)yu;
+                if (dy0 > 0.f && dy0 * dy0 > best + 0.25f) {
+                    up = false;
+                } else {
+                    if (!block_far(blkinfo[yu >> 3], dy0)) {
+                        for (int y = yu; y >= yend; --y) {
+                            const float dy = by - (float)y;
+                            if (dy > 0.f && dy * dy > best + 0.25f) {
+                                up = false;
+                                break;
+                            }
+                            scan_row(y);
+                        }
+                    }
+                    yu = yend - 1;
+                    if (yu < ymin) up = false;
+                }
             }
         }
         const float dx = bx - (float)cx, dy = by - (float)cy;
@@ -1028,7 +1090,7 @@ hipError_t hpe_launch_mesh_loss_search(const float* v2d, int B, int H, int W, in
     if (e != hipSuccess) return e;
     if (ev_a2b1) (void)hipEventRecord(ev_a2b1, st);
     if (m.grid_path) {
-        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(m.nB, B), dim3(256), (size_t)H * m.WW * 8 + (size_t)H * 4, st, m.bits, m.counts, v2d, H, W, m.WW, P,
+        hipLaunchKernelGGL(nn_b2a_rows_kernel, dim3(m.nB, B), dim3(256), (size_t)H * m.WW * 8 + (size_t)(H + (H + 7) / 8) * 4, st, m.bits, m.counts, v2d, H, W, m.WW, P,
                            m.partial, m.nblk, m.nA);
     } else {
         hipLaunchKernelGGL(nn_b2a_kernel, dim3(m.nB, B), dim3(256), 0, st, m.pts, m.counts, v2d, HW, P, m.partial, m.nblk, m.nA);
