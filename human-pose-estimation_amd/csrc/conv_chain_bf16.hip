@@ -87,22 +87,27 @@ __device__ __forceinline__ void wait_dma_leaving(int n, bool exact_counts) {
 // k, i.e. branch2c and the projection shortcut branch1 as one GEMM over [t2 | x2] with the BN scales folded into the weights (GEMM_DUAL of
 // conv_gemm_bf16.hip), followed by the next block's branch2a.
 template <int C, int CP, int NC, int C2>
-__global__ __launch_bounds__(256, 2) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
+__global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
     constexpr int BM = 64, C4 = 4 * C;
     constexpr bool HAS_RES = C2 == 0;
     constexpr int KSA = (C + C2) / 64, KSB = NC / 64, NCH = C4 / NC;
     constexpr int SLAB = BM * 128;  // bytes of one [64 rows x 64 bf16] slab
-    constexpr int QBYTES = KSB * SLAB, QBUFS = 32768 / QBYTES;
+    // residual ring: 32 KB of chunks requested ahead (identity blocks); without a residual (conv_block form) Q only stages the t3 rows
+    // of the current chunk: one buffer
+    constexpr int QBYTES = KSB * SLAB, QBUFS = HAS_RES ? 32768 / QBYTES : 1;
     constexpr int WA_SLAB = NC * 128, WB_SLAB = CP * 128;  // one k-slab of the GEMM-A / GEMM-B weights of a chunk
     constexpr int AT_OFF = 0, Q_OFF = KSA * SLAB, WA_OFF = Q_OFF + QBUFS * QBYTES, WB_OFF = WA_OFF + KSA * WA_SLAB;
-    constexpr int LDS_BYTES = WB_OFF + 16384;
+    constexpr int LDS_BYTES = WB_OFF + KSB * WB_SLAB;
     constexpr int NTA = NC / 64, NTB = CP / 64;  // 32-wide channel blocks per wave (a wave owns half the chunk / half of C')
     // vector-memory instructions per wave of each group (every wave issues a quarter of every group)
     constexpr int RI = HAS_RES ? KSB * 2 : 0, WIB = KSB * CP / 32, ST = NC / 32;  // residual chunk, GEMM-B weight slot, t3 stores of a chunk
     static_assert(C % 64 == 0 && C2 % 64 == 0 && C4 % NC == 0 && (NC == 64 || NC == 128) && (CP == 64 || CP == 128), "geometry");
-    static_assert(KSA * WA_SLAB == 16384 && KSB * WB_SLAB <= 16384 && QBUFS * QBYTES == 32768 && QBUFS <= NCH, "slot sizes");
+    static_assert(QBUFS >= 1 && QBUFS <= NCH && (!HAS_RES || QBUFS * QBYTES == 32768), "residual ring");
     static_assert(KSA * SLAB >= (CP / 64) * SLAB, "the u1 tile reuses the t2 tile's space");
-    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    // identity blocks: two workgroups per CU (72-80 KB each, ~40 KB of HBM requests in flight per workgroup).  The conv_block form has no
+    // residual ring to keep in flight (24 KB per workgroup: the [t2 | x] tile and the first weight slots), so it is built for THREE
+    // workgroups per CU (48 KB: 64-channel chunks, one Q buffer)
+    static_assert(LDS_BYTES <= (HAS_RES ? 80 : 53) * 1024, "workgroups per CU");
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 

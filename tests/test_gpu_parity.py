@@ -1098,7 +1098,7 @@ def test_bf16_chain_matches_oracle_and_two_launches(engines_bf16_chain_off_on, a
     t3, u1, occ = on.debug_chain(idx, gpu(t2), gpu(x))
     t3, u1 = cpu(t3), cpu(u1)
     print("chain kernel: resident workgroups per CU (C = 64, C = 128, conv_block form): %s" % (occ,))
-    assert min(occ) >= 2, occ
+    assert min(occ) >= 2 and occ[2] >= 3, occ
     # (ii) the two launches
     t3_two = cpu(off.debug_conv(idx, gpu(t2), residual=gpu(x), relu=True))
     u1_two = cpu(off.debug_conv(idx + 1, gpu(t3_two), relu=True))
