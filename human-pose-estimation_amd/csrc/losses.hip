@@ -332,6 +332,12 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
     const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cnt = counts[b];
+#ifdef HPE_A2B_STAMPS  // diagnostics: 100 MHz wall-clock stamps of one workgroup's phases into counter[8 ...] (tools/a2b_phases.py)
+#define A2B_STAMP(i) do { if (mfma_count && b == 5 && slice == 0 && t == 0) mfma_count[8 + (i)] = wall_clock64(); } while (0)
+#else
+#define A2B_STAMP(i) do { } while (0)
+#endif
+    A2B_STAMP(0);
     if (slice == 0)
         for (int i = nslice + t; i < nslots; i += 1024) partial[(size_t)b * nblk + i] = 0.f;
     if (cnt == 0) {
@@ -359,8 +365,10 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         const int cy = (int)fminf(fmaxf(floorf(y * (1.0f / CELL)), 0.f), gym);
         return cy * Gx + cx;
     };
+    A2B_STAMP(1);
     for (int i = t; i < P; i += 1024) atomicAdd(&sCur[cell_of(Bp[2 * i], Bp[2 * i + 1])], 1);
     __syncthreads();
+    A2B_STAMP(2);
     {
         // exclusive scan of the histogram: `per` consecutive cells per thread, wave scan, 16 wave totals
         const int per = (NC + 1023) / 1024;
@@ -401,6 +409,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
     __syncthreads();
     // A mesh concentrated in a few cells leaves nothing to prune (every tile ends up visiting most chunks, at a higher cost per
     // chunk than the full search): such an image is left to nn_a2b_mfma_kernel, launched behind this kernel for flagged images.
+    A2B_STAMP(3);
     const bool concentrated = s_occupied < min_cells;
     if (t == 0 && slice == 0) full_search[b] = concentrated ? 1 : 0;
     if (concentrated) return;
@@ -415,6 +424,7 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         sI[pos] = i;
     }
     __syncthreads();
+    A2B_STAMP(4);
     constexpr int TH = 4 * NPG;                  // tile height in pixels
     constexpr int TCX = 8 / CELL, TCY = TH / CELL;  // cells per tile edge
     static_assert(8 % CELL == 0 && TH % CELL == 0, "tiles are whole cells");
@@ -456,9 +466,8 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         bool overflow = false;  // more than three chunks tied with the best: the tile takes the explicit (distance, index) pass
         int vmask = 0;  // lane w holds bits 32w .. 32w+31 of the wave's visited-chunk set
         int nchunk = 0;  // chunks evaluated for this tile (diagnostics counter)
-        auto scan = [&](int c0, int c1) {
-            const int s = __builtin_amdgcn_readfirstlane(sStart[c0]), e = __builtin_amdgcn_readfirstlane(sStart[c1 + 1]);
-            if (e <= s) return;
+        // vertices [s, e) of the sorted array (wave-uniform), chunk by chunk
+        auto scan = [&](int s, int e) {
             for (int k = s >> 5; k <= (e - 1) >> 5; ++k) {
                 const int word = __builtin_amdgcn_readlane(vmask, k >> 5);
                 if ((word >> (k & 31)) & 1) continue;
@@ -510,12 +519,19 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
         for (int r = 0;; ++r) {
             xa = X0 - r, xb = X1 + r, ya = Y0 - r, yb = Y1 + r;
             const int xac = max(xa, 0), xbc = min(xb, Gx - 1), yac = max(ya, 0), ybc = min(yb, Gy - 1);
+            // (Round 4 tried having the lanes look the ring's cell ranges up in parallel and hand them out through readlane instead of one
+            // LDS -> SGPR round trip per range: 0.688 / 0.528 / 0.323 against 0.688 / 0.527 / 0.317 ms per call on the bench's stage-1 /
+            // stretched / evenly spread meshes -- the lookups are not what the search waits for.  Not kept.)
             for (int cy = yac; cy <= ybc; ++cy) {
+                auto one = [&](int c0, int c1) {
+                    const int s_ = __builtin_amdgcn_readfirstlane(sStart[c0]), e_ = __builtin_amdgcn_readfirstlane(sStart[c1 + 1]);
+                    if (e_ > s_) scan(s_, e_);
+                };
                 if (r == 0 || cy == ya || cy == yb) {
-                    scan(cy * Gx + xac, cy * Gx + xbc);
+                    one(cy * Gx + xac, cy * Gx + xbc);
                 } else {
-                    if (xa >= 0) scan(cy * Gx + xa, cy * Gx + xa);
-                    if (xb < Gx) scan(cy * Gx + xb, cy * Gx + xb);
+                    if (xa >= 0) one(cy * Gx + xa, cy * Gx + xa);
+                    if (xb < Gx) one(cy * Gx + xb, cy * Gx + xb);
                 }
             }
             if (xa <= 0 && xb >= Gx - 1 && ya <= 0 && yb >= Gy - 1) break;  // every cell visited
@@ -624,7 +640,9 @@ __global__ __launch_bounds__(1024) void nn_a2b_grid_kernel(const unsigned long l
     // at ~88 per microsecond -- the counted step of bench.py's loss_roofline measured 0.77 ms per search where the uncounted kernel takes
     // 0.35 ms, so `frac` was 2x pessimistic.)
     if (mfma_count && lane == 0 && wave_mfma) atomicAdd(mfma_count, (unsigned long long)wave_mfma);
+    A2B_STAMP(5);  // thread 0's wave is out of tiles
     __syncthreads();
+    A2B_STAMP(6);  // every wave is
     float acc = 0.f;
     for (int q = t; q < nq; q += 1024) acc += sTile[q];
 #pragma unroll
