@@ -486,6 +486,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(GemmArgs p) {
 // makes every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row.
 // Epilogue shared by the DMA kernel and the split-K fix-up kernel: BN scale/shift in registers, transpose through LDS,
 // rows leave as 16 B per lane with the residual read the same way.
+// The residual of an identity block is read here for the LAST time (the block input is dead after the add): -DHPE_F32_RES_NT reads it with
+// the non-temporal policy (A/B knob of round 4; the bf16 chain kernel gained 1-2 % from the same idea).
+#ifdef HPE_F32_RES_NT
+#define HPE_RES_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define HPE_RES_LOAD(ptr) (*(ptr))
+#endif
 // rpre (use_pre): the residual vectors of this thread's rows, loaded by the caller before its main loop (else they are read here)
 template <int BM, int BN, int WM, int WN, int NP>
 __device__ __forceinline__ void conv_epilogue(const GemmArgs& p, float* lds, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0, int t,
@@ -528,7 +535,7 @@ __device__ __forceinline__ void conv_epilogue(const GemmArgs& p, float* lds, f32
             f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * EP + c4]);
             if (full) {
                 if (use_pre) v += rpre[pass < NP ? pass : 0];
-                else if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n);
+                else if (p.res) v += HPE_RES_LOAD(reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + n));
                 if (p.relu) {
                     v.x = fmaxf(v.x, 0.f);
                     v.y = fmaxf(v.y, 0.f);
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_gemm_f32_dma
 #pragma unroll
             for (int pass = 0; pass < R_NPASS; ++pass) {
                 const int m = m0 + pass * R_RPP + rr_;
-                rpre[pass] = *reinterpret_cast<const f32x4*>(p.res + (size_t)(m < p.M ? m : p.M - 1) * p.ldres + n);
+                rpre[pass] = HPE_RES_LOAD(reinterpret_cast<const f32x4*>(p.res + (size_t)(m < p.M ? m : p.M - 1) * p.ldres + n));
             }
         }
     }
