@@ -1174,6 +1174,22 @@ def test_bf16_chain_encoder_matches_unchained(engines_bf16_chain_off_on, assets)
     assert np.array_equal(fb, cpu(on.encoder(big)).astype(np.float64))  # bitwise repeatable
 
 
+def test_bf16_chain_repeatable_under_concurrency(engines_bf16_chain_off_on):
+    """The chained launches synchronise with COUNTED vmcnt waits (every wave issues a quarter of every DMA group; what may stay in flight
+    is counted per barrier) and fall back to vmcnt(0) on a partial last tile.  A wrong count shows as a now-and-then wrong tile once many
+    workgroups stretch the DMA latency, so: the whole encoder 40 times at B = 256 (two concurrent chunks of 128; 12,544 / 3,136 tiles per
+    launch) and 40 times at B = 100 (two chunks of 50: 50 x 784 = 612.5 tiles of 64 pixels on the 28 x 28 maps, the partial-tile path under
+    load), every repeat bitwise equal to the first and the first within the bf16 tolerance of the unchained plan."""
+    off, on = engines_bf16_chain_off_on
+    for B, seed in ((256, 93), (100, 94)):
+        img = gpu(synthetic.make_images(B, seed=seed))
+        first = cpu(on.encoder(img))
+        ref = cpu(off.encoder(img)).astype(np.float64)
+        assert float(np.linalg.norm(first - ref) / np.linalg.norm(ref)) < 2e-3
+        for rep in range(40):
+            assert np.array_equal(cpu(on.encoder(img)), first), (B, rep)
+
+
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
 @pytest.mark.parametrize("variant", ["survey", "bounded"])
 @pytest.mark.parametrize("B", [64, 256])
