@@ -11,7 +11,7 @@
 // Rounding points are those of the two-launch path: t3 is rounded to bf16 where it is stored, and the second GEMM multiplies exactly
 // those bf16 values; only the fp32 summation order inside a k-slab differs.
 //
-// Structure (one workgroup = 64 pixels x all 4C channels, 4 waves, two workgroups per CU):
+// Structure (one workgroup = 64 pixels x all 4C channels, 4 waves, two workgroups per CU; three in the conv_block form):
 //   * the workgroup walks the 4C axis in chunks of NC channels (128 in stage 2, 64 in stage 3).  Per chunk: GEMM-A (64 x NC, K = C) from
 //     the resident t2 tile, epilogue IN PLACE on the residual chunk that LDS-DMA has put in the A-operand slab layout (so the result is
 //     at once the bytes to store and the A operand of the next GEMM), 16-B row stores of t3, GEMM-B partial sums (64 x C', K = NC of
@@ -22,9 +22,11 @@
 //     tile and a 32 KB ring of residual chunks (all of them in stage 2, four of eight in stage 3; refilled as chunks retire) -- two
 //     workgroups per CU keep ~100 KB in flight.  The weights of a chunk (16 KB for GEMM-A, 16 KB for GEMM-B, L2 hits) have one slot
 //     each and are requested as soon as the previous chunk has released the slot.
-//   * vmcnt is per wave and counts in issue order, so the roles are split by wave: wave 0 streams the weight slots (waited at every
-//     barrier that needs one), wave 1 writes the t3 rows (never waits), waves 2-3 issue the activation DMAs and wait with a COUNTED
-//     vmcnt for the oldest residual chunk only (their queue holds loads only, which retire in order).
+//   * every wave issues a QUARTER of every DMA group and of the t3 stores (one loader wave only reaches ~25 GB/s; a version with
+//     dedicated loader waves was slower), so all four waves hold the same queue, and every barrier is preceded by a COUNTED vmcnt
+//     wait that names exactly what may stay in flight behind the youngest thing the barrier publishes (vmcnt is per wave and counts
+//     LDS-DMA, loads and stores together, in issue order); the issue order is fixed in the prologue comment below.  On the last,
+//     partial tile the counts are not exact (skipped stores) and every wait drains the queue.
 //   * every wait in front of a barrier that publishes LDS-DMA data is written out: hipcc's __syncthreads() only waits for lgkmcnt
 //     behind some DMA patterns and for vmcnt(0) behind others (rounds 3-4).
 #include <hip/hip_runtime.h>
@@ -62,8 +64,8 @@ __device__ __forceinline__ void dma16_nt(const void* src, void* lds_dst) {
 }
 
 // Barriers are written out: __syncthreads() is a workgroup fence + s_barrier, and behind pending LDS-DMA hipcc puts a vmcnt(0) in
-// front of some of them (here: the one after the in-place epilogue, which would make waves 2-3 wait for the residual chunk they have
-// only just requested) and only lgkmcnt(0) in front of others.  lds_barrier: LDS traffic of this wave is done, DMAs stay in flight;
+// front of some of them (here: the one after the in-place epilogue, which would make the waves wait for the residual chunk and the
+// weight slot they have only just requested) and only lgkmcnt(0) in front of others.  lds_barrier: LDS traffic of this wave is done, DMAs stay in flight;
 // the caller adds wait_dma() where the barrier publishes this wave's LDS-DMA data.
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
