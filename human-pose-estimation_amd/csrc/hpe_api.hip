@@ -463,8 +463,15 @@ hipError_t run_dual(hpe_ctx* c, int i2c, int i1, const float* t2, const float* x
 // `first`: the conv_block form -- branch2c + the projection shortcut branch1 (idx i2c + 1, stride 1: stage 2 only) as the dual-source GEMM,
 // chained with the next block's branch2a (idx i2c + 2); bit 2 of chain_fuse
 bool use_chain(const hpe_ctx* c, int stg, int i2c, bool first, bool has_next) {
-    if (!c->bf16 || !has_next) return false;
+    if (!has_next) return false;
     const ConvSpec& s2 = specs()[i2c];
+    if (!c->bf16) {
+        // fp32: identity blocks of stage 2 only (conv_chain_f32.hip; bit 3 of chain_fuse, on by default: A/B on two boxes +0.3 ... +1.4 % at
+        // B = 256, +1.6 % at B = 64)
+        if (first || stg != 0 || !(c->chain_fuse & 8)) return false;
+        const ConvSpec& sn = specs()[i2c + 1];
+        return sn.kh == 1 && sn.stride == 1 && sn.cin == s2.cout && hpe_chain_f32_supported(s2.cin, s2.cout, sn.cout);
+    }
     if (first) {
         const ConvSpec& s1 = specs()[i2c + 1];
         const ConvSpec& sn = specs()[i2c + 2];
@@ -477,12 +484,31 @@ bool use_chain(const hpe_ctx* c, int stg, int i2c, bool first, bool has_next) {
 }
 
 // res: the block input -- the residual of an identity block, the second A source of a conv_block
-hipError_t run_chain(hpe_ctx* c, int i2c, bool first, const float* t2, const float* res, int B, float* t3, float* u1, hipStream_t st) {
+hipError_t run_chain(hpe_ctx* c, int i2c, bool first, const float* t2, const float* res, int B, float* t3, float* u1, hipStream_t st,
+                     bool u1_slab8 = false) {
     const ConvSpec& s2 = specs()[i2c];
     const int inext = i2c + (first ? 2 : 1);
     const ConvSpec& sn = specs()[inext];
     const ConvLayer& L2 = c->conv[i2c];
     const ConvLayer& Ln = c->conv[inext];
+    if (!c->bf16) {
+        ChainArgsF32 q{};
+        q.t2 = t2;
+        q.res = res;
+        q.w2c = L2.w;
+        q.w2a = Ln.w;
+        q.scaleA = L2.scale;
+        q.shiftA = L2.shift;
+        q.scaleB = Ln.scale;
+        q.shiftB = Ln.shift;
+        q.t3 = t3;
+        q.u1 = u1;
+        q.M = B * s2.hout * s2.hout;
+        q.ldw2c = L2.k_pad;
+        q.ldw2a = Ln.k_pad;
+        q.u1_slab8 = u1_slab8 ? 1 : 0;
+        return hpe_launch_chain_f32(q, s2.cin, s2.cout, sn.cout, st);
+    }
     ChainArgs p{};
     p.t2 = reinterpret_cast<const __bf16*>(t2);
     if (first) {
@@ -606,7 +632,10 @@ hipError_t encoder_chunk(hpe_ctx* c, const float* images, int i0, int B, float* 
                 // launch; the 4C-wide sum is written once and not read back (timed as layer i2c; the next branch2a then shows 0)
                 const bool t2 = c->timing >= 2;
                 if (t2) HIPE(hipEventRecord(c->cev0[i2c], st));
-                HIPE(run_chain(c, i2c, first, T2, cur, B, nxt, T1, st));
+                // (fp32: the next block's 3x3 layer may be the fused Winograd kernel, which reads its input channel-slab major)
+                const int i2b_next = i2c + (first ? 3 : 2);
+                const bool slab8_next = !c->bf16 && (use_wino_fused(c, i2b_next, B) || use_wino4_fused(c, i2b_next, B));
+                HIPE(run_chain(c, i2c, first, T2, cur, B, nxt, T1, st, slab8_next));
                 if (t2) {
                     HIPE(hipEventRecord(c->cev1[i2c], st));
                     if (first) {  // the projection shortcut is inside the launch
@@ -936,7 +965,7 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
         c->wino4_ksplit = opt(c->cfg.wino4_ksplit, "HPE_WINO4_KSPLIT", 1);
-        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 7) & 7) : 0;
+        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 7) & 7) : (opt(c->cfg.chain_fuse, "HPE_CHAIN", 8) & 8);
         c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");
@@ -1700,9 +1729,21 @@ int hpe_debug_conv(hpe_ctx* c, int idx, const float* x, int B, const float* resi
 int hpe_debug_chain(hpe_ctx* c, int idx2c, const float* t2, const float* residual, int B, float* t3, float* u1, int* occupancy, void* stream) {
     int rc = check_ready(c, B, NEED_ENC);
     if (rc) return rc;
-    if (!c->bf16) return fail(HPE_ERR_STATE, "hpe_debug_chain works on bf16 contexts only");
     if (idx2c < 1 || idx2c + 2 >= HPE_NUM_CONV || !t2 || !residual || !t3 || !u1) return fail(HPE_ERR_INVALID, "bad argument");
     const ConvSpec& s2 = specs()[idx2c];
+    if (!c->bf16) {
+        // fp32 contexts: the identity blocks of stage 2 (conv_chain_f32.hip); operands used in place, u1 row-major
+        const ConvSpec& sn1 = specs()[idx2c + 1];
+        if (s2.kh != 1 || sn1.kh != 1 || sn1.stride != 1 || sn1.cin != s2.cout || !hpe_chain_f32_supported(s2.cin, s2.cout, sn1.cout))
+            return fail(HPE_ERR_INVALID, "hpe_debug_chain (fp32): idx2c must be res2b_branch2c (an identity block of stage 2 followed by an identity block)");
+        DeviceGuard g32(c->cfg.device);
+        HIP_TRY(run_chain(c, idx2c, false, t2, residual, B, t3, u1, static_cast<hipStream_t>(stream), false));
+        if (occupancy) {
+            occupancy[0] = occupancy[1] = occupancy[2] = 0;
+            HIP_TRY(hpe_chain_f32_occupancy(&occupancy[0]));
+        }
+        return HPE_OK;
+    }
     // the conv_block form when idx2c is the branch2c of a block's first unit (its branch1 follows in the layer table)
     const bool first = specs()[idx2c + 1].kh == 1 && specs()[idx2c + 1].cout == s2.cout && strstr(specs()[idx2c + 1].name, "branch1") != nullptr;
     const ConvSpec& sn = specs()[idx2c + (first ? 2 : 1)];

@@ -97,6 +97,16 @@ struct ChainArgs {
 bool hpe_chain_bf16_supported(int C, int C4, int CP, int C2);
 hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, int C2, hipStream_t st);
 hipError_t hpe_chain_bf16_occupancy(int out[3]);
+// conv_chain_f32.hip: the same chained launch in fp32 (identity blocks of stage 2, C = 64; opt-in).  u1_slab8: u1 is written channel-slab
+// major, u1[(n / 8) * M + m][n % 8] (what the fused Winograd 3x3 kernel of the next block reads)
+struct ChainArgsF32 {
+    const float *t2, *res, *w2c, *w2a, *scaleA, *shiftA, *scaleB, *shiftB;
+    float *t3, *u1;
+    int M, ldw2c, ldw2a, u1_slab8;
+};
+bool hpe_chain_f32_supported(int C, int C4, int CP);
+hipError_t hpe_launch_chain_f32(const ChainArgsF32& p, int C, int C4, int CP, hipStream_t st);
+hipError_t hpe_chain_f32_occupancy(int* out);
 hipError_t hpe_launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);  // round to nearest even
 hipError_t hpe_launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t st);
 hipError_t hpe_launch_pad_input_bf16(const float* img, void* out, int B, int H, int W, int Hp, int Wp, hipStream_t st);

@@ -83,7 +83,9 @@ typedef struct HpeConfig {
     int chain_fuse;        /* HPE_CHAIN            bf16 encoder: stages (1 = stage 2, 2 = stage 3) whose identity blocks run res*_branch2c + add +
                             *                      ReLU and the NEXT block's res*_branch2a + ReLU as one launch: the 4C-wide block output is
                             *                      written once and not read back; 4 = the same for res2a (branch2c + branch1 + add + ReLU, the
-                            *                      dual-source GEMM, + res2b_branch2a) (7); same bf16 rounding points as the separate launches */
+                            *                      dual-source GEMM, + res2b_branch2a) (7); same bf16 rounding points as the separate launches.
+                            *                      fp32 encoder: 8 = res2b_branch2c + add + ReLU and res2c_branch2a + ReLU as one launch
+                            *                      (conv_chain_f32.hip) (8); 0 = one launch per layer */
 } HpeConfig;
 
 /* defaults: struct_size = sizeof(HpeConfig), device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1.
@@ -233,7 +235,8 @@ int hpe_debug_conv(hpe_ctx* ctx, int idx, const float* x_dev, int B, const float
  * identity block: t2_dev [B,H,H,C], residual_dev [B,H,H,4C] (rounded to bf16 on the way in) -> t3_dev [B,H,H,4C] =
  * relu(bn(conv2c(t2)) + residual) and u1_dev [B,H,H,C] = relu(bn(conv2a_next(t3))), both widened to float.  idx2c = res2a_branch2c: the
  * conv_block form, residual_dev is the block INPUT [B,56,56,64] and t3 = relu(bn(conv2c(t2)) + bn(conv1(input))).  occupancy (host,
- * optional, 3 ints): resident workgroups per CU of the three instantiations (the design needs 2). */
+ * optional, 3 ints): resident workgroups per CU of the three instantiations (the design needs 2).  fp32 contexts: idx2c = res2b_branch2c
+ * only (conv_chain_f32.hip), operands in fp32, occupancy[0] = that kernel's. */
 int hpe_debug_chain(hpe_ctx* ctx, int idx2c, const float* t2_dev, const float* residual_dev, int B, float* t3_dev, float* u1_dev,
                     int* occupancy, void* stream);
 /* The fused stem kernel alone (conv1_pad + conv1 + bn_conv1 + ReLU + pool1_pad + MaxPooling2D(3,2) of the Keras ResNet50,

@@ -1190,6 +1190,58 @@ def test_bf16_chain_repeatable_under_concurrency(engines_bf16_chain_off_on):
             assert np.array_equal(cpu(on.encoder(img)), first), (B, rep)
 
 
+# ------------------------------------------------------------------------------------------- fp32 chained 1x1 launch (round 4, opt-in)
+@pytest.fixture(scope="module")
+def engine_f32_chain(assets):
+    e = encoder_engine(assets, 256, chain_fuse=8)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_f32_chain_matches_oracle_and_two_launches(engine_f32_chain, assets, B):
+    """conv_chain_f32.hip (res2b_branch2c + add + ReLU and res2c_branch2a + ReLU as one launch, fp32) against the fp64 oracle (the
+    per-kernel bar of the fp32 conv layers: 5e-6 of the largest output) and against the two separate launches (summation order only)."""
+    idx = resnet_spec.CONV_INDEX["res2b_branch2c"]
+    s, sn = resnet_spec.CONV_SPECS[idx], resnet_spec.CONV_SPECS[idx + 1]
+    g = np.random.Generator(np.random.Philox(2600 + B))
+    t2 = np.maximum(g.normal(0, 1, (B, 56, 56, s.cin)), 0).astype(np.float32)
+    x = np.maximum(g.normal(0, 2, (B, 56, 56, s.cout)), 0).astype(np.float32)
+    t2[0, 0, 0, :] = 20.0
+    engine = engine_f32_chain
+    t3, u1, occ = engine.debug_chain(idx, gpu(t2), gpu(x))
+    t3, u1 = cpu(t3), cpu(u1)
+    assert occ[0] >= 2, occ
+    t3_two = cpu(engine.debug_conv(idx, gpu(t2), residual=gpu(x), relu=True))
+    u1_two = cpu(engine.debug_conv(idx + 1, gpu(t3_two), relu=True))
+    assert rel(t3, t3_two) < 2e-6 and rel(u1, u1_two) < 2e-6, (rel(t3, t3_two), rel(u1, u1_two))
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    scn, shn = _bn_fold(p, sn)
+    ref3 = np.maximum(O.conv2d_nhwc(t2, p[s.name + "/kernel"], p[s.name + "/bias"], 1, 0, dtype=np.float64) * sc + sh + x.astype(np.float64), 0)
+    ref1 = np.maximum(O.conv2d_nhwc(ref3, p[sn.name + "/kernel"], p[sn.name + "/bias"], 1, 0, dtype=np.float64) * scn + shn, 0)
+    assert rel(t3, ref3) < 5e-6 and rel(u1, ref1) < 5e-6, (rel(t3, ref3), rel(u1, ref1))
+
+
+def test_f32_chain_encoder_matches_default_and_is_repeatable(engine_f32_chain, assets):
+    """The fp32 encoder with the chained launch on the identity blocks of stage 2 (chain_fuse=8; the next block's fused Winograd kernel
+    reads the chained u1 channel-slab major): features against the default plan and the oracle; 40 repeats at B = 256 and B = 100
+    bitwise equal (counted vmcnt waits under concurrency, partial tiles: 100 x 3136 pixels are whole tiles, so B = 37 runs too)."""
+    on = engine_f32_chain
+    off = encoder_engine(assets, 256, chain_fuse=0)
+    img = gpu(synthetic.make_images(3, seed=95))
+    fo, fn = cpu(off.encoder(img)).astype(np.float64), cpu(on.encoder(img)).astype(np.float64)
+    ref = O.resnet50_features(cpu(img), assets["enc"]).astype(np.float64)
+    assert rel(fn, fo) < 2e-6 and rel(fn, ref) < TOL, (rel(fn, fo), rel(fn, ref))
+    for B, seed in ((256, 96), (100, 97), (37, 98)):
+        big = gpu(synthetic.make_images(B, seed=seed))
+        first = cpu(on.encoder(big))
+        assert rel(first, cpu(off.encoder(big))) < 5e-6
+        for rep in range(40 if B > 37 else 5):
+            assert np.array_equal(cpu(on.encoder(big)), first), (B, rep)
+    off.close()
+
+
 # ------------------------------------------------------------------------------------------- full size (B = 256) properties
 @pytest.mark.parametrize("variant", ["survey", "bounded"])
 @pytest.mark.parametrize("B", [64, 256])

@@ -10,7 +10,8 @@ python bench.py --steps 30 --warmup 5 --batch 64 $Q 2>/dev/null > $OUT/bench_fp3
 HPE_POWER_TRACE=$OUT/power_trace_bf16.csv python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 --cpu-sample 16 --no-legs 2>/dev/null > $OUT/bench_bf16.json
 python bench.py --steps 10 --warmup 3 --config5 --cpu-sample 0 2>/dev/null > $OUT/bench_config5.json
 python bench.py --steps 10 --warmup 3 --config5 --regressor survey --cpu-sample 0 --sustain 0 2>/dev/null > $OUT/bench_config5_survey_regressor.json
-# round 4: the bf16 encoder without the chained 1x1 launches (one launch per layer), same box
+# round 4: the encoders without the chained 1x1 launches (one launch per layer), same box
+HPE_CHAIN=0 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_chain_off.json
 HPE_CHAIN=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_chain_off.json
 HPE_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_rccl_world1.json
 HPE_FORCE_DIST=1 python bench.py --steps 30 --warmup 5 $Q --encoder-dtype bf16 2>/dev/null > $OUT/bench_bf16_rccl_world1.json
@@ -20,8 +21,8 @@ python bench.py --steps 20 --warmup 5 $Q --no-pipeline 2>/dev/null > $OUT/bench_
 python bench.py --steps 20 --warmup 5 $Q --graph 2>/dev/null > $OUT/bench_fp32_graph.json
 python bench.py --steps 20 --warmup 5 $Q --from-host 2>/dev/null > $OUT/bench_fp32_from_host.json
 # the round-2 plan (F(2x2) Winograd only) and the round-1 structure on the same box
-HPE_WINO_F4=0 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_r2_plan.json
-HPE_WINO_F4=0 HPE_STEM_FUSED=0 HPE_DUAL=0 HPE_WIDE128_MIN_TILES=0 python bench.py --steps 20 --warmup 5 $Q --no-pipeline 2>/dev/null > $OUT/bench_fp32_r1_structure.json
+HPE_WINO_F4=0 HPE_CHAIN=0 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_r2_plan.json
+HPE_WINO_F4=0 HPE_CHAIN=0 HPE_STEM_FUSED=0 HPE_DUAL=0 HPE_WIDE128_MIN_TILES=0 python bench.py --steps 20 --warmup 5 $Q --no-pipeline 2>/dev/null > $OUT/bench_fp32_r1_structure.json
 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q 2>$OUT/layers_fp32.txt > /dev/null
 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q --encoder-dtype bf16 2>$OUT/layers_bf16.txt > /dev/null
 HPE_CHAIN=0 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q --encoder-dtype bf16 2>$OUT/layers_bf16_chain_off.txt > /dev/null
