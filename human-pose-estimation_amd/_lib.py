@@ -45,10 +45,11 @@ class HpeConfig(C.Structure):
         ("bf16_p8", C.c_int),
         ("wino4_ksplit", C.c_int),
         ("chain_fuse", C.c_int),
+        ("halo3", C.c_int),
     ]
 
 
-PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4", "wino4_fused", "bf16_p8", "wino4_ksplit", "chain_fuse")
+PLAN_OPTIONS = ("n_streams", "dual_gemm", "stem_fused", "wino_min_c", "wino_min_items", "wino_fused", "wino_fused_min_hw", "mesh_a2b", "wino_f4", "wino4_fused", "bf16_p8", "wino4_ksplit", "chain_fuse", "halo3")
 
 
 class HpeSmplModel(C.Structure):

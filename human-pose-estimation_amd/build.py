@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpe_hip.so")
-SOURCES = ["conv_gemm.hip", "conv_gemm_bf16.hip", "conv_gemm_bf16_p8.hip", "conv_chain_bf16.hip", "conv_chain_f32.hip", "conv_wino.hip", "conv_wino4.hip", "stem_fused.hip", "encoder_ops.hip", "smpl.hip", "losses.hip", "prepost.hip", "hpe_api.hip"]
+SOURCES = ["conv_gemm.hip", "conv_gemm_bf16.hip", "conv_gemm_bf16_p8.hip", "conv_chain_bf16.hip", "conv_chain_f32.hip", "conv3_halo_bf16.hip", "conv_wino.hip", "conv_wino4.hip", "stem_fused.hip", "encoder_ops.hip", "smpl.hip", "losses.hip", "prepost.hip", "hpe_api.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-fast-math"]
 
 

@@ -88,12 +88,16 @@ __device__ __forceinline__ void wait_dma_leaving(int n, bool exact_counts) {
 // C2 > 0: the conv_block form -- no residual; the expand GEMM has a second A source x2 [M, C2] (the block input, stride 1) behind t2 along
 // k, i.e. branch2c and the projection shortcut branch1 as one GEMM over [t2 | x2] with the BN scales folded into the weights (GEMM_DUAL of
 // conv_gemm_bf16.hip), followed by the next block's branch2a.
-template <int C, int CP, int NC, int C2>
-__global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
-    constexpr int BM = 64, C4 = 4 * C;
+// BM = pixels per workgroup: 64 (4 waves, two or three workgroups per CU) or 128 (8 waves, ONE workgroup per CU with all 160 KB of LDS:
+// stage 4, where a chunk's weights are 64 KB -- twice the pixels per workgroup halve the weight stream per pixel).
+template <int C, int CP, int NC, int C2, int BM = 64>
+__global__ __launch_bounds__(BM * 4, BM == 128 ? 2 : (C2 > 0 ? 3 : 2)) void chain_expand_reduce_bf16_kernel(ChainArgs p) {
+    constexpr int C4 = 4 * C;
+    constexpr int NW = BM / 16;    // waves: wave (wm, wn) owns pixels 32 wm .. + 31 and one half of the channels
+    constexpr int NTHR = 64 * NW;
     constexpr bool HAS_RES = C2 == 0;
     constexpr int KSA = (C + C2) / 64, KSB = NC / 64, NCH = C4 / NC;
-    constexpr int SLAB = BM * 128;  // bytes of one [64 rows x 64 bf16] slab
+    constexpr int SLAB = BM * 128;  // bytes of one [BM rows x 64 bf16] slab
     // residual ring: 32 KB of chunks requested ahead (identity blocks); without a residual (conv_block form) Q only stages the t3 rows
     // of the current chunk: one buffer
     constexpr int QBYTES = KSB * SLAB, QBUFS = HAS_RES ? 32768 / QBYTES : 1;
@@ -102,14 +106,15 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
     constexpr int LDS_BYTES = WB_OFF + KSB * WB_SLAB;
     constexpr int NTA = NC / 64, NTB = CP / 64;  // 32-wide channel blocks per wave (a wave owns half the chunk / half of C')
     // vector-memory instructions per wave of each group (every wave issues a quarter of every group)
-    constexpr int RI = HAS_RES ? KSB * 2 : 0, WIB = KSB * CP / 32, ST = NC / 32;  // residual chunk, GEMM-B weight slot, t3 stores of a chunk
-    static_assert(C % 64 == 0 && C2 % 64 == 0 && C4 % NC == 0 && (NC == 64 || NC == 128) && (CP == 64 || CP == 128), "geometry");
+    constexpr int RI = HAS_RES ? KSB * 2 : 0, WIB = KSB * CP / (8 * NW), ST = (BM * NC / 8) / NTHR;  // residual chunk, GEMM-B weight slot, t3 stores
+    static_assert(C % 64 == 0 && C2 % 64 == 0 && C4 % NC == 0 && (NC == 64 || NC == 128) && CP % 64 == 0 && (BM == 64 || BM == 128), "geometry");
+    static_assert(NC % (8 * NW) == 0 && CP % (8 * NW) == 0 && (BM * NC / 8) % NTHR == 0 && (BM * CP / 8) % NTHR == 0, "every wave issues an equal share");
     static_assert(QBUFS >= 1 && QBUFS <= NCH && (!HAS_RES || QBUFS * QBYTES == 32768), "residual ring");
     static_assert(KSA * SLAB >= (CP / 64) * SLAB, "the u1 tile reuses the t2 tile's space");
     // identity blocks: two workgroups per CU (72-80 KB each, ~40 KB of HBM requests in flight per workgroup).  The conv_block form has no
     // residual ring to keep in flight (24 KB per workgroup: the [t2 | x] tile and the first weight slots), so it is built for THREE
     // workgroups per CU (48 KB: 64-channel chunks, one Q buffer)
-    static_assert(LDS_BYTES <= (HAS_RES ? 80 : 53) * 1024, "workgroups per CU");
+    static_assert(LDS_BYTES <= (BM == 128 ? 160 : (HAS_RES ? 80 : 53)) * 1024, "workgroups per CU");
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -126,14 +131,14 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
     //      (l & 7) ^ ((row >> 1) & 7) (the swizzle the fragment reads undo).  Every address is a wave-uniform base (SGPR pair) + a
     //      32-bit per-lane byte offset (64-bit per-lane addresses for every unrolled DMA cost 255 VGPRs).
     const int drow = lane >> 3;
-    // Every wave issues a quarter of every group: instructions ii = wave, wave + 4, ... (rows 8 ii .. + 7).  The swizzle term
-    // ((row >> 1) & 7) = (4 ii + (drow >> 1)) & 7 depends on the parity of ii only, i.e. on the wave.
+    // Every wave issues an equal share of every group: instructions ii = wave, wave + NW, ... (rows 8 ii .. + 7).  The swizzle term
+    // ((row >> 1) & 7) = (4 ii + (drow >> 1)) & 7 depends on the parity of ii only, i.e. on the wave (NW is even).
     const int r0 = 8 * wave + drow;
     const unsigned swz_a = (((lane & 7) ^ ((r0 >> 1) & 7)) * 8) * 2;
-    unsigned off_t2[2], off_res[2], off_x2[2];  // activation rows r0, r0 + 32, clamped to M - 1 on the last tile
+    unsigned off_t2[2], off_res[2], off_x2[2];  // activation rows r0, r0 + 8 NW, clamped to M - 1 on the last tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int m = m0 + r0 + 32 * i;
+        int m = m0 + r0 + 8 * NW * i;
         if (m >= p.M) m = p.M - 1;
         off_t2[i] = (unsigned)m * (C * 2) + swz_a;
         off_res[i] = (unsigned)m * (C4 * 2) + swz_a;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const char* src = s < C / 64 ? T2b + s * 128 + off_t2[i] : X2b + (s - C / 64) * 128 + off_x2[i];
-                dma16(src, lds + AT_OFF + s * SLAB + (wave + 4 * i) * 1024);
+                dma16(src, lds + AT_OFF + s * SLAB + (wave + NW * i) * 1024);
             }
     };
     auto issue_res = [&](int c) {  // residual chunk c -> Q[c % QBUFS]: KSB slabs
@@ -161,15 +166,15 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
         for (int s = 0; s < KSB; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                dma16_nt(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + (c % QBUFS) * QBYTES + s * SLAB + (wave + 4 * i) * 1024);
+                dma16_nt(RESb + (c * NC + s * 64) * 2 + off_res[i], lds + Q_OFF + (c % QBUFS) * QBYTES + s * SLAB + (wave + NW * i) * 1024);
     };
     auto issue_wa = [&](int c) {  // W2c rows [c * NC, + NC), all KSA k-slabs -> slot A
 #pragma unroll
         for (int s = 0; s < KSA; ++s) {
             const char* base = WAb + ((size_t)(c * NC) * p.ldw2c + s * 64) * 2;
 #pragma unroll
-            for (int i = 0; i < NC / 32; ++i)
-                dma16(base + (size_t)(32 * i) * p.ldw2c * 2 + off_wa, lds + WA_OFF + s * WA_SLAB + (wave + 4 * i) * 1024);
+            for (int i = 0; i < NC / (8 * NW); ++i)
+                dma16(base + (size_t)(8 * NW * i) * p.ldw2c * 2 + off_wa, lds + WA_OFF + s * WA_SLAB + (wave + NW * i) * 1024);
         }
     };
     auto issue_wb = [&](int c) {  // W2a' rows [0, CP), k-slabs of chunk c -> slot B
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
         for (int s = 0; s < KSB; ++s) {
             const char* base = WBb + (c * NC + s * 64) * 2;
 #pragma unroll
-            for (int i = 0; i < CP / 32; ++i)
-                dma16(base + (size_t)(32 * i) * p.ldw2a * 2 + off_wb, lds + WB_OFF + s * WB_SLAB + (wave + 4 * i) * 1024);
+            for (int i = 0; i < CP / (8 * NW); ++i)
+                dma16(base + (size_t)(8 * NW * i) * p.ldw2a * 2 + off_wb, lds + WB_OFF + s * WB_SLAB + (wave + NW * i) * 1024);
         }
     };
 
@@ -289,8 +294,8 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
             const unsigned char* Q = lds + Q_OFF + qb * QBYTES;
             constexpr int UPR = NC / 8;  // 16-B units per row
 #pragma unroll
-            for (int pass = 0; pass < (BM * UPR) / 256; ++pass) {
-                const int idx = pass * 256 + t;
+            for (int pass = 0; pass < (BM * UPR) / NTHR; ++pass) {
+                const int idx = pass * NTHR + t;
                 const int r = idx / UPR, u = idx - r * UPR;
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(Q + (u >> 3) * SLAB + r * 128 + (((u & 7) ^ ((r >> 1) & 7)) << 4));
                 const int m = m0 + r;
@@ -348,8 +353,8 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
         constexpr int UPR = CP / 8;  // 16-B units per row
         const unsigned char* U = lds + AT_OFF;
 #pragma unroll
-        for (int pass = 0; pass < (BM * UPR) / 256; ++pass) {
-            const int idx = pass * 256 + t;
+        for (int pass = 0; pass < (BM * UPR) / NTHR; ++pass) {
+            const int idx = pass * NTHR + t;
             const int r = idx / UPR, u = idx - r * UPR;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(U + (u >> 3) * SLAB + r * 128 + (((u & 7) ^ ((r >> 1) & 7)) << 4));
             const int m = m0 + r;
@@ -358,10 +363,10 @@ __global__ __launch_bounds__(256, C2 > 0 ? 3 : 2) void chain_expand_reduce_bf16_
     }
 }
 
-template <int C, int CP, int NC, int C2>
+template <int C, int CP, int NC, int C2, int BM = 64>
 hipError_t launch_chain(const ChainArgs& p, hipStream_t st) {
-    const int grid = (p.M + 63) / 64;
-    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP, NC, C2>), dim3(grid), dim3(256), 0, st, p);
+    const int grid = (p.M + BM - 1) / BM;
+    hipLaunchKernelGGL((chain_expand_reduce_bf16_kernel<C, CP, NC, C2, BM>), dim3(grid), dim3(BM * 4), 0, st, p);
     return hipGetLastError();
 }
 
@@ -370,7 +375,7 @@ hipError_t launch_chain(const ChainArgs& p, hipStream_t st) {
 // C2 = 0: identity block (residual); C2 > 0: conv_block with a stride-1 projection shortcut over C2 input channels (stage 2)
 bool hpe_chain_bf16_supported(int C, int C4, int CP, int C2) {
     if (C4 != 4 * C || CP != C) return false;
-    return C2 == 0 ? (C == 64 || C == 128) : (C == 64 && C2 == 64);
+    return C2 == 0 ? (C == 64 || C == 128 || C == 256) : (C == 64 && C2 == 64);
 }
 
 hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, int C2, hipStream_t st) {
@@ -382,6 +387,7 @@ hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, int 
         return hipErrorInvalidValue;
     if (C2 > 0) return launch_chain<64, 64, 64, 64>(p, st);
     if (C == 64) return launch_chain<64, 64, 128, 0>(p, st);
+    if (C == 256) return launch_chain<256, 256, 64, 0, 128>(p, st);
     return launch_chain<128, 128, 64, 0>(p, st);
 }
 

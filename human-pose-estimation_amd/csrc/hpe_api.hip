@@ -200,6 +200,7 @@ struct hpe_ctx {
     unsigned pipe_idx = 0;
     float* feat_alt = nullptr;
     int wino4_ksplit = 1;  // plan option wino4_ksplit / HPE_WINO4_KSPLIT
+    int halo3 = 0;         // bf16 only: map sizes (1 = 7x7, 2 = 14x14, 4 = 28x28, 8 = 56x56) whose 3x3 layers run on conv3_halo_bf16.hip; plan option halo3 / HPE_HALO3
     int chain_fuse = 0;    // bf16 only: stages (bit 0: stage 2, bit 1: stage 3) whose identity blocks run branch2c + the next block's branch2a as
                            // one launch (conv_chain_bf16.hip); plan option chain_fuse / HPE_CHAIN
     int co_running = 1;    // chunk streams of the encoder call being enqueued (launch-size rules of the F(4x4) kernels)
@@ -413,6 +414,21 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
     } else {
         mode = GEMM_STRIDED;
     }
+    if (c->bf16 && mode == GEMM_CONV3 && !res && s.stride == 1 && (c->halo3 & f4_bit(s.hin) ? true : false) &&
+        hpe_halo3_bf16_supported(s.hin, s.cin, s.cout) && L.k_pad >= 9 * s.cin)
+    {
+        Halo3Args h{};
+        h.x = reinterpret_cast<const __bf16*>(x);
+        h.w = reinterpret_cast<const __bf16*>(L.w);
+        h.scale = L.scale;
+        h.shift = L.shift;
+        h.y = reinterpret_cast<__bf16*>(y);
+        h.M = p.M;
+        h.N = s.cout;
+        h.ldw = L.k_pad;
+        h.relu = relu;
+        return hpe_launch_halo3_bf16(h, s.hin, s.cin, st);
+    }
     if (c->bf16) {
         p.cin_slabs = s.cin / 64;
         const Bf16Plan pl = pick_bf16(c->knobs, p.M, p.N, p.K, mode == GEMM_DENSE && res != nullptr && s.cout == 4 * s.cin, (flags & CONV_CONCURRENT) != 0, mode);
@@ -478,7 +494,9 @@ bool use_chain(const hpe_ctx* c, int stg, int i2c, bool first, bool has_next) {
         return stg == 0 && (c->chain_fuse & 4) && c->conv[i2c].w_dual && s1.stride == 1 && s1.hin == s2.hin && sn.kh == 1 && sn.stride == 1 &&
                sn.cin == s2.cout && c->conv[i2c].k_dual == s2.cin + s1.cin && hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout, s1.cin);
     }
-    if (!((c->chain_fuse >> stg) & 1)) return false;
+    // identity blocks: bit 0 = stage 2, bit 1 = stage 3, bit 4 (value 16) = stage 4 (128-pixel workgroups, one per CU)
+    const int bit = stg == 0 ? 1 : stg == 1 ? 2 : stg == 2 ? 16 : 0;
+    if (!(c->chain_fuse & bit)) return false;
     const ConvSpec& sn = specs()[i2c + 1];
     return sn.kh == 1 && sn.stride == 1 && sn.cin == s2.cout && hpe_chain_bf16_supported(s2.cin, s2.cout, sn.cout, 0);
 }
@@ -777,7 +795,7 @@ void hpe_config_init(HpeConfig* cfg) {
     cfg->bn_eps = 1e-3f;
     cfg->encoder_dtype = 0;
     cfg->n_streams = cfg->dual_gemm = cfg->stem_fused = cfg->wino_min_c = cfg->wino_min_items = cfg->wino_fused = -1;
-    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = cfg->wino4_ksplit = cfg->chain_fuse = -1;
+    cfg->wino_fused_min_hw = cfg->mesh_a2b = cfg->wino_f4 = cfg->wino4_fused = cfg->bf16_p8 = cfg->wino4_ksplit = cfg->chain_fuse = cfg->halo3 = -1;
 }
 
 int hpe_create(const HpeConfig* cfg, hpe_ctx** out) {
@@ -965,7 +983,8 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino_f4 = c->wino_min_c > 0 ? opt(c->cfg.wino_f4, "HPE_WINO_F4", 7) : 0;
         c->wino4_min_items = opt(-1, "HPE_WINO4_MIN_ITEMS", c->wino4_min_items);
         c->wino4_ksplit = opt(c->cfg.wino4_ksplit, "HPE_WINO4_KSPLIT", 1);
-        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 7) & 7) : (opt(c->cfg.chain_fuse, "HPE_CHAIN", 8) & 8);
+        c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 7) & 23) : (opt(c->cfg.chain_fuse, "HPE_CHAIN", 8) & 8);
+        c->halo3 = c->bf16 ? (opt(c->cfg.halo3, "HPE_HALO3", 15) & 15) : 0;
         c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");

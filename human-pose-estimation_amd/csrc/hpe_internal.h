@@ -94,6 +94,19 @@ struct ChainArgs {
     __bf16* u1;  // [M, C']
     int M, ldw2c, ldw2a;
 };
+// conv3_halo_bf16.hip: 3x3 / stride 1 / SAME, bf16, activation tile + halo resident in LDS (the 9 taps read one staged image)
+struct Halo3Args {
+    const __bf16* x;     // [M, Cin] NHWC, M = B * HW * HW
+    const __bf16* w;     // packed [N][ldw], k = tap * Cin + c
+    const float* scale;  // [N]
+    const float* shift;  // [N]
+    __bf16* y;           // [M, N]
+    int M, N, ldw, relu;
+    int n_ntiles;        // filled by the launcher
+};
+bool hpe_halo3_bf16_supported(int HW, int Cin, int N);
+hipError_t hpe_launch_halo3_bf16(const Halo3Args& p, int HW, int Cin, hipStream_t st);
+
 bool hpe_chain_bf16_supported(int C, int C4, int CP, int C2);
 hipError_t hpe_launch_chain_bf16(const ChainArgs& p, int C, int C4, int CP, int C2, hipStream_t st);
 hipError_t hpe_chain_bf16_occupancy(int out[3]);

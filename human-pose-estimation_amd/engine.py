@@ -36,7 +36,7 @@ def _require_cuda_tensor(t, name, shape_tail=None):
 class HpeEngine(object):
     def __init__(self, device=0, max_batch=8, num_stage=3, bn_eps=1e-3, encoder_dtype="fp32", **plan_options):
         """plan_options: the HpeConfig plan fields of include/hpe.h (n_streams, dual_gemm, stem_fused, wino_min_c, wino_min_items,
-        wino_fused, wino_fused_min_hw, mesh_a2b, wino_f4, wino4_fused, bf16_p8, wino4_ksplit, chain_fuse); unset = -1 = the library default (environment variable, else built-in).
+        wino_fused, wino_fused_min_hw, mesh_a2b, wino_f4, wino4_fused, bf16_p8, wino4_ksplit, chain_fuse, halo3); unset = -1 = the library default (environment variable, else built-in).
         They select WHICH kernels run, per context -- two engines with different options can coexist in one process."""
         self.lib = _lib.load()
         torch = _torch()

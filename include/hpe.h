@@ -85,7 +85,12 @@ typedef struct HpeConfig {
                             *                      written once and not read back; 4 = the same for res2a (branch2c + branch1 + add + ReLU, the
                             *                      dual-source GEMM, + res2b_branch2a) (7); same bf16 rounding points as the separate launches.
                             *                      fp32 encoder: 8 = res2b_branch2c + add + ReLU and res2c_branch2a + ReLU as one launch
-                            *                      (conv_chain_f32.hip) (8); 0 = one launch per layer */
+                            *                      (conv_chain_f32.hip) (8); 16 = bf16 stage 4 too (one 128-pixel workgroup per CU; a
+                            *                      measured tie, off); 0 = one launch per layer */
+    int halo3;             /* HPE_HALO3            bf16 encoder: map sizes whose 3x3 layers run on the halo-resident kernel (conv3_halo_bf16.hip:
+                            *                      the activation tile + halo staged in LDS once per 64 input channels, the 9 taps read it at 9
+                            *                      row shifts) instead of the implicit GEMM: bit mask as wino_f4 (1 = 7x7 ... 8 = 56x56) (15); same
+                            *                      operands and rounding points, fp32 summation order differs */
 } HpeConfig;
 
 /* defaults: struct_size = sizeof(HpeConfig), device 0, max_batch 8, num_stage 3, bn_eps 1e-3, fp32, every plan option -1.

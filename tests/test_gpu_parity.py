@@ -1070,18 +1070,98 @@ def test_bf16_p8_encoder_matches_round2_encoder(engines_bf16_old_and_p8, assets)
     assert float(np.linalg.norm(fn - fo) / np.linalg.norm(fo)) < 3e-3
 
 
-# ------------------------------------------------------------------------------------------- bf16 chained 1x1 launches (round 4)
+# ------------------------------------------------------------------------------------------- bf16 halo-resident 3x3 kernel (round 4)
 @pytest.fixture(scope="module")
-def engines_bf16_chain_off_on(assets):
-    """Two bf16 encoder contexts: every layer its own launch (chain_fuse=0) and the blocks of stages 2-3 (identity blocks, and the conv_block
-    res2a) with branch2c + the next block's branch2a as one launch (chain_fuse=7, the default)."""
-    made = [encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=0), encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=7)]
+def engines_bf16_halo_off_on(assets):
+    """Two bf16 encoder contexts: the 3x3 layers on the implicit GEMM (halo3=0) and on conv3_halo_bf16.hip for every map size (halo3=15)."""
+    made = [encoder_engine(assets, 256, encoder_dtype="bf16", halo3=0), encoder_engine(assets, 256, encoder_dtype="bf16", halo3=15)]
     yield made
     for e in made:
         e.close()
 
 
-@pytest.mark.parametrize("name", ["res2b_branch2c", "res3b_branch2c", "res3c_branch2c"])
+@pytest.mark.parametrize("name", ["res2b_branch2b", "res3c_branch2b", "res4d_branch2b", "res5b_branch2b"])
+@pytest.mark.parametrize("B", [1, 3, 37])
+def test_bf16_halo3_layer_matches_oracle(engines_bf16_halo_off_on, assets, name, B):
+    """One 3x3 layer through conv3_halo_bf16_kernel against the fp64 convolution of the same bf16-rounded operands and against the round-2
+    implicit-GEMM kernel (fp32 summation order differs: at most one bf16 ulp).  Pixel tiles of 256 (128 on the 7 x 7 maps) cut images at
+    arbitrary rows (49 B / 196 B / 784 B / 3136 B pixels: partial last tile unless B is a multiple of 256 / 64 / 16 / 4), image borders
+    fall inside tiles (every tap mask pattern), the first and last tiles clamp their halo rows at the ends of the buffer."""
+    off, on = engines_bf16_halo_off_on
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    g = np.random.Generator(np.random.Philox(2500 + idx + B))
+    x = g.normal(0, 1, (B, s.hin, s.hin, s.cin)).astype(np.float32)
+    x[g.random(x.shape) < 0.3] = 0.0
+    x[0, 0, 0, :] = 20.0                      # corners: only 4 of the 9 taps see them
+    x[-1, -1, -1, :] = -20.0
+    x[:, 0, :, 0] += 3.0                      # an edge row / column with a large mean: a tap that wraps to the neighbouring row shows
+    x[:, :, -1, 1] -= 3.0
+    y_new = cpu(on.debug_conv(idx, gpu(x), relu=True))
+    y_old = cpu(off.debug_conv(idx, gpu(x), relu=True))
+    p = assets["enc"]
+    sc, sh = _bn_fold(p, s)
+    lin = O.conv2d_nhwc(_bf16_round(x), _bf16_round(p[s.name + "/kernel"]), p[s.name + "/bias"], 1, 1, dtype=np.float64) * sc + sh
+    ref = np.maximum(lin, 0)
+    assert y_new.shape == ref.shape
+    ulp = 2.0 ** -8
+    assert rel(y_new, ref) < ulp and rel(y_old, ref) < ulp, (rel(y_new, ref), rel(y_old, ref))
+    assert float(np.linalg.norm(y_new - ref) / np.linalg.norm(ref)) < 2.5e-3
+    assert rel(y_new, y_old) < ulp
+    # no ReLU: the sign of the pre-activation survives
+    y_lin = cpu(on.debug_conv(idx, gpu(x), relu=False))
+    assert rel(y_lin, lin) < ulp and float(y_lin.min()) < 0
+
+
+@pytest.mark.parametrize("name", ["res2c_branch2b", "res3b_branch2b", "res4f_branch2b", "res5c_branch2b"])
+def test_bf16_halo3_full_size_layer_equals_round2_kernel(engines_bf16_halo_off_on, name):
+    """The metric batch (256 images; 3136 / 784 / 196 x 2 / 98 x 4 workgroups) against the oracle-checked round-2 kernel, and bitwise
+    repeatable (counted vmcnt waits: a wrong count shows as a now-and-then wrong tile under load)."""
+    off, on = engines_bf16_halo_off_on
+    idx = resnet_spec.CONV_INDEX[name]
+    s = resnet_spec.CONV_SPECS[idx]
+    g = np.random.Generator(np.random.Philox(2700 + idx))
+    x = gpu(np.maximum(g.normal(0, 1, (256, s.hin, s.hin, s.cin)), 0).astype(np.float32))
+    y_new = cpu(on.debug_conv(idx, x, relu=True))
+    y_old = cpu(off.debug_conv(idx, x, relu=True))
+    assert rel(y_new, y_old) < 2.0 ** -8
+    assert float(np.linalg.norm(y_new - y_old) / np.linalg.norm(y_old)) < 1e-3
+    for rep in range(10):
+        assert np.array_equal(cpu(on.debug_conv(idx, x, relu=True)), y_new), rep
+
+
+def test_bf16_halo3_encoder_matches_round2_encoder(engines_bf16_halo_off_on, assets):
+    """Whole bf16 encoder with all sixteen 3x3 layers on the halo-resident kernel: features within the bf16 tolerance of the implicit-GEMM
+    plan and of the rounding-point-emulating oracle; one chunk, two concurrent chunks, repeats bitwise equal."""
+    off, on = engines_bf16_halo_off_on
+    img = gpu(synthetic.make_images(5, seed=95))
+    fo, fn = cpu(off.encoder(img)).astype(np.float64), cpu(on.encoder(img)).astype(np.float64)
+    l2 = float(np.linalg.norm(fn - fo) / np.linalg.norm(fo))
+    print("bf16 halo-3x3 encoder vs implicit GEMM: rel-L2 %.3g" % l2)
+    assert l2 < 2e-3
+    ref = O.resnet50_features(cpu(img[:2]), assets["enc"], act_round="bf16", bf16_folded=BF16_FOLDED)
+    assert float(np.linalg.norm(fn[:2] - ref) / np.linalg.norm(ref)) < 3e-3
+    for B, seed in ((256, 96), (100, 97)):
+        big = gpu(synthetic.make_images(B, seed=seed))
+        fb = cpu(on.encoder(big))
+        fo = cpu(off.encoder(big)).astype(np.float64)
+        assert float(np.linalg.norm(fb - fo) / np.linalg.norm(fo)) < 2e-3
+        for rep in range(20):
+            assert np.array_equal(cpu(on.encoder(big)), fb), (B, rep)
+
+
+# ------------------------------------------------------------------------------------------- bf16 chained 1x1 launches (round 4)
+@pytest.fixture(scope="module")
+def engines_bf16_chain_off_on(assets):
+    """Two bf16 encoder contexts: every layer its own launch (chain_fuse=0) and the blocks of stages 2-3 (identity blocks, and the conv_block
+    res2a; with bit 16 also the identity blocks of stage 4) with branch2c + the next block's branch2a as one launch (chain_fuse=23)."""
+    made = [encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=0), encoder_engine(assets, 256, encoder_dtype="bf16", chain_fuse=23)]
+    yield made
+    for e in made:
+        e.close()
+
+
+@pytest.mark.parametrize("name", ["res2b_branch2c", "res3b_branch2c", "res3c_branch2c", "res4b_branch2c", "res4e_branch2c"])
 @pytest.mark.parametrize("B", [1, 3, 37])
 def test_bf16_chain_matches_oracle_and_two_launches(engines_bf16_chain_off_on, assets, name, B):
     """conv_chain_bf16.hip: t3 = relu(bn(W2c t2) + x), u1 = relu(bn'(W2a' t3)) in one launch against (i) the fp64 evaluation of the same

@@ -4,7 +4,7 @@
 OUT=${1:-gpurun_out/chain}; shift
 MASKS=${@:-0 7}
 mkdir -p $OUT
-python tools/layer_times.py 256 5 --all -- off=dtype:bf16,chain_fuse:0 on=dtype:bf16,chain_fuse:7 > $OUT/layers_chain.txt 2>&1 || exit 1
+python tools/layer_times.py 256 5 --all -- off=dtype:bf16,chain_fuse:0 on=dtype:bf16,chain_fuse:7 s4=dtype:bf16,chain_fuse:23 > $OUT/layers_chain.txt 2>&1 || exit 1
 for m in $MASKS; do
   HPE_CHAIN=$m python bench.py --encoder-dtype bf16 --steps 20 --warmup 5 --cpu-sample 0 --sustain 0 --no-legs \
       > $OUT/bench_bf16_chain_$m.json 2> $OUT/bench_bf16_chain_$m.err || exit 1
