@@ -38,6 +38,26 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Fragment reads are inline asm with COUNTED lgkmcnt waits.  hipcc never emits a counted lgkmcnt in a kernel that issues LDS-DMA inside
+// the loop (a global_load_lds is a FLAT-encoded instruction that touches LDS; LLVM's waitcnt pass then treats the counter as unordered
+// and falls back to lgkmcnt(0) -- checked on a six-line kernel).  lgkmcnt(0) in front of the multiplies of a group also waits for the
+// reads of the NEXT group that have just been issued: both waves of a SIMD then sit in LDS latency with an idle matrix pipe (rocprofv3:
+// SQ_WAIT_ANY 38 % of the wave cycles, although neither the DMA waits nor the barriers cost anything -- removing both changed the layer
+// times by < 3 %).  LDS operations of a wave return in order, so "all but the youngest MT + NT" is exact.  The compiler does not know
+// that the asm results arrive late: tools/isa_lint.py replays the lgkmcnt queue over the disassembly and fails the build check if any
+// instruction reads a fragment register between its ds_read and the wait that covers it (a register copy inserted by the allocator).
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// the multiplies that follow consume the operands: tying them to the wait keeps every use behind it
+#define HPE_LGKM_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define HPE_LGKM_WAIT3(N, a, b, c) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c))
+#define HPE_LGKM_WAIT12(N, a, b, c, d, e, f, g, h, i, j, k, l) \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j), "+v"(k), "+v"(l))
+
 // all but the wave's n youngest vector-memory operations are done; n is a compile-time constant after unrolling
 __device__ __forceinline__ void wait_dma_leaving(int n) {
     switch (n) {
@@ -75,7 +95,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
     constexpr int MT = 2, NT = BN / 64;    // wave tile: 64 pixels x BN / 2 channels
     constexpr int SLAB = BM * 128;         // output staging: [BM rows x 64 channels]
     static_assert(CIN % 64 == 0 && BN % 64 == 0 && BN % (8 * NW) == 0 && (BM == 128 || BM == 256), "geometry");
-    static_assert(NSW == 4 && (CS <= 4 || CS % 4 == 0), "ring positions are compile-time constants: 9 = 1 mod 4, period 4 slabs");
+    static_assert(NSW == 4 && (CS <= 4 || (CS % 4 == 0 && NT == 2)), "ring positions are compile-time constants: 9 = 1 mod 4, period 4 slabs");
     static_assert(CS == 1 || API <= 6, "the pieces of the next image are requested one per step, taps 0 .. API-1, and are older than W(cs + 1, 0)");
     static_assert((BN / 64) * SLAB <= LDS_BYTES && LDS_BYTES <= 160 * 1024 && NSW * W_BYTES <= 65536, "LDS");
     static_assert((BM * BN / 8) % NTHR == 0, "row stores");
@@ -158,8 +178,9 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // fragments of one 16-deep group: two register sets, the group after the current one is read from LDS while the current one multiplies
-    bf16x8 fa[2][MT], fw[2][NT];
+    // fragments of one 16-deep group: three register sets, the two groups after the current one are being read from LDS while the current
+    // one multiplies (group G = 4 tap + g of a slab uses set G % 3; a slab has 36 groups, so the set is a compile-time constant)
+    bf16x8 fa[3][MT], fw[3][NT];
     unsigned aoff[MT], ax[MT];  // image row address / swizzle term of the step whose fragments are read next
     auto tap_addr = [&](int cs, int tap) {
         const int shift = (tap / 3 - 1) * HW + (tap % 3 - 1);
@@ -172,15 +193,39 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
             asm volatile("" : "+v"(ar));
             const int lr = ar + shift;
             const bool ok = (amask[i] >> tap) & 1u;
-            aoff[i] = ok ? (unsigned)(abuf + lr * 128) : (unsigned)ZERO_OFF;
-            ax[i] = ok ? (unsigned)((lr >> 1) & 7) : 0u;
+            // an out-of-image tap reads the 256 B of zeros at the SAME bank slot its image row would have used (row parity and swizzle
+            // term kept): the 16-lane groups of ds_read_b128 stay conflict-free (with one shared zero address 17-24 % of the LDS cycles
+            // of these kernels were bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+            aoff[i] = ok ? (unsigned)(abuf + lr * 128) : (unsigned)(ZERO_OFF + ((lr & 1) << 7));
+            ax[i] = (unsigned)((lr >> 1) & 7);
         }
     };
+    const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) unsigned char*)lds);
     auto load_frags = [&](int set, int wbuf, int g) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(lds + aoff[i] + (((2 * g + hi) ^ ax[i]) << 4));
+        for (int i = 0; i < MT; ++i) fa[set][i] = lds_read16<0>(lds_base + aoff[i] + (((2 * g + hi) ^ ax[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fw[set][j] = *reinterpret_cast<const bf16x8*>(lds + W_OFF + wbuf * W_BYTES + wfrag[j][g]);
+        for (int j = 0; j < NT; ++j) {
+            const unsigned a = lds_base + (unsigned)wfrag[j][g];
+            switch (wbuf) {  // a constant in every unrolled copy: the ring position goes into the immediate offset
+                case 0: fw[set][j] = lds_read16<W_OFF>(a); break;
+                case 1: fw[set][j] = lds_read16<W_OFF + W_BYTES>(a); break;
+                case 2: fw[set][j] = lds_read16<W_OFF + 2 * W_BYTES>(a); break;
+                default: fw[set][j] = lds_read16<W_OFF + 3 * W_BYTES>(a); break;
+            }
+        }
+    };
+    static_assert(MT == 2 && (NT == 1 || NT == 2), "a fragment group is MT + NT reads: the counted lgkmcnt waits below");
+    auto wait_frags = [&](int set, int groups_in_flight) {  // group `set` has landed; the 2 / 1 / 0 groups read after it may still be in flight
+        if constexpr (NT == 2) {
+            if (groups_in_flight == 2) HPE_LGKM_WAIT4(8, fa[set][0], fa[set][1], fw[set][0], fw[set][1]);
+            else if (groups_in_flight == 1) HPE_LGKM_WAIT4(4, fa[set][0], fa[set][1], fw[set][0], fw[set][1]);
+            else HPE_LGKM_WAIT4(0, fa[set][0], fa[set][1], fw[set][0], fw[set][1]);
+        } else {
+            if (groups_in_flight == 2) HPE_LGKM_WAIT3(6, fa[set][0], fa[set][1], fw[set][0]);
+            else if (groups_in_flight == 1) HPE_LGKM_WAIT3(3, fa[set][0], fa[set][1], fw[set][0]);
+            else HPE_LGKM_WAIT3(0, fa[set][0], fa[set][1], fw[set][0]);
+        }
     };
 
     // ---- prologue.  Issue ORDER (what the counted waits rely on): image 0 (API), W(0) .. W(2); then in the middle of step s: W(s + 3),
@@ -194,6 +239,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
     lds_barrier();
     tap_addr(0, 0);
     load_frags(0, 0, 0);
+    load_frags(1, 0, 1);
 
     // One input slab = 9 steps of 4 fragment groups.  The step's barrier sits between groups 0 and 1 and is about the NEXT step: "W(s + 1)
     // has landed everywhere, every wave is past step s - 1" -- so the fragments of step s + 1's first group are read (group 3 of step s)
@@ -212,24 +258,42 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
                     const int tail = tap + 2 < 9 ? WI : 0;  // last slab: no image pieces; W(s + 2) exists while tap + 2 < 9
                     if (CS > 1 && !last) wait_dma_leaving(steady);
                     else wait_dma_leaving(tail);
-                    lds_barrier();
+                    asm volatile("s_barrier" ::: "memory");  // (no lgkmcnt drain: this wave's reads of older steps were waited for before their multiplies)
                     const int t3 = tap + NSW - 1;
                     if (t3 < 9) issue_w(cs, t3, (R0 + t3) % NSW);
                     else if (!last) issue_w(cs + 1, t3 - 9, (R0 + t3) % NSW);
                     if (CS > 1 && !last && tap < API) issue_a_piece(cs + 1, tap);
                 }
-                // read the next group: (tap, g + 1), or the first group of the next step
-                if (g < 3) {
-                    load_frags((g + 1) & 1, (R0 + tap) % NSW, g + 1);
-                } else if (!(last && tap == 8)) {
-                    if (tap < 8) tap_addr(cs, tap + 1);
-                    else tap_addr(cs + 1, 0);
-                    load_frags(0, (R0 + tap + 1) % NSW, 0);
+                // read the group two ahead -- (tap, g + 2), or group g - 2 of the next step -- then wait for the current one only
+                constexpr bool LOOPED = CS > 4;  // Cin = 512: the slab groups are a run-time loop and `last` a run-time flag
+                const int G = 4 * tap + g, cur = G % 3, nxt = (G + 2) % 3;
+                if (g < 2) {
+                    load_frags(nxt, (R0 + tap) % NSW, g + 2);
+                    wait_frags(cur, 2);
+                } else if (tap < 8) {
+                    if (g == 2) tap_addr(cs, tap + 1);
+                    load_frags(nxt, (R0 + tap + 1) % NSW, g - 2);
+                    wait_frags(cur, 2);
+                } else if (LOOPED && R0 == NSW - 1) {
+                    // The back edge of the slab-group loop (and, on the last pass, the end).  Nothing may cross it in flight: the register
+                    // copies the compiler places on a back edge or a branch would copy fragments that have not landed (tools/isa_lint.py
+                    // found exactly that).  So no branch here: the next groups are read unconditionally -- after the last slab those are
+                    // reads of valid LDS that nobody uses -- and at the edge all three sets are waited for.
+                    if (g == 2) tap_addr(cs + 1, 0);
+                    load_frags(nxt, (R0 + tap + 1) % NSW, g - 2);
+                    if (g == 2) wait_frags(cur, 2);
+                    else HPE_LGKM_WAIT12(0, fa[0][0], fa[0][1], fw[0][0], fw[0][NT - 1], fa[1][0], fa[1][1], fw[1][0], fw[1][NT - 1], fa[2][0], fa[2][1], fw[2][0], fw[2][NT - 1]);
+                } else if (last) {  // (a compile-time constant in the unrolled kernels): the last two groups of the kernel
+                    wait_frags(cur, g == 2 ? 1 : 0);
+                } else {
+                    if (g == 2) tap_addr(cs + 1, 0);
+                    load_frags(nxt, (R0 + tap + 1) % NSW, g - 2);
+                    wait_frags(cur, 2);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[g & 1][j], fa[g & 1][i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
             }
         }
     };

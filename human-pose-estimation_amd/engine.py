@@ -486,7 +486,9 @@ class HpeEngine(object):
                     "(the 13 3x3 layers on the 28x28 / 14x14 / 7x7 maps as fp32 Winograd F(4x4,3x3); F(2x2,3x3) / direct below 64 work "
                     "items) + wino_fused_kernel (the three 56x56 3x3 layers, F(2x2,3x3)) + stem_fused_f32_kernel -- the 53 conv layers of one "
                     "step, priced at their direct-convolution FLOPs")
-        return "conv_gemm_bf16_dma_kernel -- the 53 conv layers of one step, priced at their algorithmic HBM bytes"
+        return ("conv_gemm_bf16_dma_kernel (1x1 / strided / dual-source layers) + chain_expand_reduce_bf16_kernel (branch2c + next branch2a of "
+                "stages 2-3 as one launch) + conv3_halo_bf16_kernel (the sixteen 3x3 layers, tile + halo resident in LDS) + stem_fused_bf16_kernel "
+                "-- the 53 conv layers of one step, priced at their algorithmic HBM bytes")
 
     def enable_timing(self, level=1):
         _lib.check(self.lib.hpe_enable_timing(self._h, int(level)))

@@ -1,5 +1,6 @@
 """CPU-side ISA lint (tools/isa_lint.py): every kernel of the in-tree objects that uses LDS-DMA (`global_load_lds`) has an `s_waitcnt`
-naming vmcnt on every control-flow path from a DMA to an `s_barrier`.  A compiler upgrade (or an edit) that drops such a wait -- the
+naming vmcnt on every control-flow path from a DMA to an `s_barrier`, and no instruction names the destination of an LDS read that its
+lgkmcnt waits have not retired yet (the inline-asm fragment reads of conv3_halo_bf16.hip).  A compiler upgrade (or an edit) that drops such a wait -- the
 round-3 race of conv_wino4.hip -- fails here, in the build container, not on the GPU box."""
 import glob
 import os
@@ -43,6 +44,27 @@ def test_lint_follows_branches():
     # the wait sits in only one arm of a branch (the round-3 pattern: wave-uniform DMA issue, wait emitted on one path)
     arm = _mk([dma, ("s_cbranch_vccz", "1"), ("s_waitcnt", "vmcnt(0)"), ("s_barrier", ""), ("s_endpgm", "")])
     assert isa_lint.lint_kernel(arm) == [0x100C]
+
+
+def test_lgkm_replay_flags_a_fragment_register_named_before_its_wait():
+    """The second rule: inline-asm LDS reads with counted lgkmcnt waits (conv3_halo_bf16.hip).  LDS reads return in order; a register is
+    safe once the wait leaves fewer younger operations outstanding than were issued after its read."""
+    rd = lambda d, a: ("ds_read_b128", "v[%d:%d], v%d" % (d, d + 3, a))  # noqa: E731
+    mfma = ("v_mfma_f32_32x32x16_bf16", "v[40:55], v[0:3], v[4:7], v[40:55]")
+    # two groups in flight, lgkmcnt(2) retires the older one: the multiply may use v[0:7]
+    ok = _mk([rd(0, 30), rd(4, 31), rd(8, 30), rd(12, 31), ("s_waitcnt", "lgkmcnt(2)"), mfma, ("s_waitcnt", "lgkmcnt(0)"), ("s_endpgm", "")])
+    assert isa_lint.lint_lgkm_hazard(ok) == []
+    # the same with a wait that leaves three outstanding: v[4:7] has not landed
+    late = _mk([rd(0, 30), rd(4, 31), rd(8, 30), rd(12, 31), ("s_waitcnt", "lgkmcnt(3)"), mfma, ("s_endpgm", "")])
+    assert [(a, m) for a, m, _ in isa_lint.lint_lgkm_hazard(late)] == [(0x1014, "v_mfma_f32_32x32x16_bf16")]
+    # a register copy between the read and its wait (what the allocator did on a loop back edge)
+    copy = _mk([rd(0, 30), ("v_mov_b64_e32", "v[20:21], v[2:3]"), ("s_waitcnt", "lgkmcnt(0)"), ("s_endpgm", "")])
+    assert [(a, m, r) for a, m, r in isa_lint.lint_lgkm_hazard(copy)] == [(0x1004, "v_mov_b64_e32", 2)]
+    # address registers of a pending read may be reused; an outstanding scalar load makes counted waits inexact (only lgkmcnt(0) retires)
+    addr = _mk([rd(0, 30), ("v_add_u32_e32", "v30, 1, v30"), ("s_waitcnt", "lgkmcnt(0)"), ("v_mov_b32_e32", "v9, v0"), ("s_endpgm", "")])
+    assert isa_lint.lint_lgkm_hazard(addr) == []
+    smem = _mk([("s_load_dwordx2", "s[4:5], s[0:1], 0x0"), rd(0, 30), rd(4, 31), ("s_waitcnt", "lgkmcnt(1)"), ("v_mov_b32_e32", "v9, v0"), ("s_endpgm", "")])
+    assert len(isa_lint.lint_lgkm_hazard(smem)) == 1
 
 
 def test_objects_have_a_vmcnt_wait_between_every_dma_and_barrier():

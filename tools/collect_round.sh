@@ -13,6 +13,9 @@ python bench.py --steps 10 --warmup 3 --config5 --regressor survey --cpu-sample 
 # round 4: the encoders without the chained 1x1 launches (one launch per layer), same box
 HPE_CHAIN=0 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_chain_off.json
 HPE_CHAIN=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_chain_off.json
+# round 4: the bf16 encoder with its 3x3 layers on the implicit GEMM (halo3 = 0), same box
+HPE_HALO3=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_halo3_off.json
+HPE_HALO3=0 HPE_CHAIN=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_r3_plan.json
 HPE_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_rccl_world1.json
 HPE_FORCE_DIST=1 python bench.py --steps 30 --warmup 5 $Q --encoder-dtype bf16 2>/dev/null > $OUT/bench_bf16_rccl_world1.json
 HPE_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 $Q --config5 2>/dev/null > $OUT/bench_config5_rccl_world1.json
@@ -26,6 +29,7 @@ HPE_WINO_F4=0 HPE_CHAIN=0 HPE_STEM_FUSED=0 HPE_DUAL=0 HPE_WIDE128_MIN_TILES=0 py
 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q 2>$OUT/layers_fp32.txt > /dev/null
 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q --encoder-dtype bf16 2>$OUT/layers_bf16.txt > /dev/null
 HPE_CHAIN=0 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q --encoder-dtype bf16 2>$OUT/layers_bf16_chain_off.txt > /dev/null
+HPE_HALO3=0 HPE_BENCH_LAYERS=1 HPE_CONCURRENT_TILES=1 python bench.py --steps 5 --warmup 2 $Q --encoder-dtype bf16 2>$OUT/layers_bf16_halo3_off.txt > /dev/null
 python tools/latency_bench.py 2>/dev/null | grep "B=" > $OUT/latency_small_batch.txt
 python tools/latency_breakdown.py 2>/dev/null | grep "B=" > $OUT/latency_breakdown.txt
 for m in grid mfma; do echo "== HPE_MESH_A2B=$m"; HPE_MESH_A2B=$m python tools/mesh_loss_bench.py 2>/dev/null; done > $OUT/mesh_loss_search.txt

@@ -120,6 +120,56 @@ def lint_kernel(insns):
     return sorted(bad)
 
 
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    out = set()
+    for m in _VREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lint_lgkm_hazard(insns):
+    """Replay the lgkmcnt queue of a wave over the instruction stream (program order of the text: the software-pipelined loops here
+    carry the same registers in flight over the back edge as their prologue puts in flight): an LDS read returns its data when an
+    `s_waitcnt lgkmcnt(N)` leaves at most N younger operations outstanding.  Any instruction that names a destination register of a read
+    that is still outstanding uses stale data (or is overtaken by the returning data).  hipcc keeps this invariant for the reads it
+    manages; the inline-asm reads with counted waits of conv3_halo_bf16.hip are invisible to it -- a register copy that the allocator
+    puts between such a read and its wait is what this rule catches.  Returns [(address, mnemonic, register)]."""
+    queue = []  # outstanding lgkm operations in issue order: set of destination VGPRs (empty: ds_write, LDS atomics without return ...)
+    smem = 0    # scalar loads outstanding: they return out of order, only lgkmcnt(0) retires them for sure
+    bad = []
+    for addr, _, mn, ops in insns:
+        if mn == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ops)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    queue, smem = [], 0
+                elif smem == 0:
+                    del queue[: max(0, len(queue) - n)]
+            continue
+        pending = set().union(*queue) if queue else set()
+        is_ds = mn.startswith("ds_")
+        parts = [x.strip() for x in ops.split(",")] if ops else []
+        dest = _vregs(parts[0]) if (is_ds and mn.startswith("ds_read") and parts) else set()
+        used = _vregs(",".join(parts[1:])) if dest else _vregs(ops)
+        hit = (used | dest) & pending
+        if hit:
+            bad.append((addr, mn, min(hit)))
+        if is_ds:
+            queue.append(dest)
+        elif mn.startswith("s_load") or mn.startswith("s_buffer_load"):
+            smem += 1
+        elif mn.startswith("flat_") and not mn.startswith("flat_store"):
+            queue.append(set())  # FLAT loads count in lgkmcnt too; none in this library
+    return bad
+
+
 def lint_object(obj):
     """[(kernel symbol, [barrier addresses])] for the kernels of one object that violate the rule; also returns how many kernels use LDS-DMA"""
     kernels = parse_kernels(device_disassembly(obj))
@@ -130,6 +180,9 @@ def lint_object(obj):
         b = lint_kernel(insns)
         if b:
             bad.append((name, b))
+        h = lint_lgkm_hazard(insns)
+        if h:
+            bad.append((name + " [register of an outstanding LDS read named before its lgkmcnt wait: %s v%d]" % (h[0][1], h[0][2]), [x[0] for x in h]))
     return bad, n_dma
 
 
@@ -138,7 +191,8 @@ def main():
     rc = 0
     for o in objs:
         bad, n_dma = lint_object(o)
-        print("%-28s %3d LDS-DMA kernels, %d with a DMA -> s_barrier path that has no vmcnt wait" % (os.path.basename(o), n_dma, len(bad)))
+        print("%-28s %3d LDS-DMA kernels, %d findings (DMA -> s_barrier path without a vmcnt wait / LDS read used before its lgkmcnt wait)"
+              % (os.path.basename(o), n_dma, len(bad)))
         for name, addrs in bad:
             rc = 1
             print("    %s: s_barrier at %s" % (name, ", ".join("0x%x" % a for a in addrs[:8])))

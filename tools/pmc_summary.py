@@ -111,7 +111,7 @@ def main():
             print("\nconv family (encoder launches before the average pool, profiler attached, chunk streams off): %d launches, %.3f ms; "
                   "algorithmic %.1f GFLOP (direct-convolution FLOPs) -> %.1f TFLOP/s = %.3f of 157.3 TFLOP/s"
                   % (len(enc_rows), enc_ms, gf, gf / enc_ms, gf / enc_ms / 157.3))
-    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("w4_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream") or k.startswith("chain_")]
+    conv = [k for k in t if k.startswith("conv_gemm") or k.startswith("wino_") or k.startswith("w4_") or k.startswith("stem_fused") or k.startswith("conv1x1_stream") or k.startswith("chain_") or k.startswith("conv3_halo")]
     cf = sum(fetch.get(k, 0.0) for k in conv)
     cw = sum(write.get(k, 0.0) for k in conv)
     print("\nJSON " + json.dumps({"fetch_bytes_corrected": cf, "write_bytes": cw, "total_bytes": cf + cw, "kernels": sorted(conv)}))
