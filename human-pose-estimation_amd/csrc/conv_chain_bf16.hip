@@ -31,6 +31,7 @@
 //     behind some DMA patterns and for vmcnt(0) behind others (rounds 3-4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hpe_internal.h"
 

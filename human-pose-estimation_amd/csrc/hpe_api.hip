@@ -128,6 +128,7 @@ struct TileKnobs {
     int wide128_min_tiles = 384;  // HPE_WIDE128_MIN_TILES: 1.5 tiles per CU (0 = the round-1 rule everywhere)
     int force_expand = -1;   // HPE_EXPAND_TILE: fp32 tile of the identity-block expand layers (experiment knob)
     int expand_small_grid = 128;  // HPE_EXPAND_SMALL_GRID: expand layers with fewer 128x64 tiles than this take the 64x64 split-K tile (0 = never)
+    int bf16_w8_min_tiles = 128;  // HPE_BF16_W8_MIN_TILES: N > 64 bf16 launches with >= this many 128 x 128 tiles use the 8-wave tile (0 = never)
     int force_ns_bf16 = -1;  // HPE_NS_BF16: LDS ring depth of the bf16 GEMM (2..4), -1 = per-layer rule
     int bf16_rules = 1;      // HPE_BF16_RULES=0: the round-1 tile rule (128x128 / 64x128 by grid size, double buffer)
     int bf16_p8 = 0;         // HPE_BF16_P8: layer kinds that take the 256 x 256 phase-interleaved kernel (bit mask, see pick_bf16)
@@ -302,6 +303,11 @@ Bf16Plan pick_bf16(const TileKnobs& kn, int M, int N, int K, bool residual_expan
         if (kn.bf16_rules) {
             if (residual_expand) pl.tile = TILE_128x64_W8;
             else if (M <= 16384 && M >= 8192 && K >= 1024 && N >= 256) pl.tile = TILE_256x128_W8;
+            // Round 4: these launches are paced by the ISSUE of their LDS-DMA instructions (60-180 cycles each for the issuing wave),
+            // not by the matrix pipe (without any multiplies the 1x1 layers take 0.96-0.99 of their time; a deeper ring is slower):
+            // the 128 x 128 tile with EIGHT waves halves the DMA instructions per wave and slab.  Every N > 64 layer of the B = 256
+            // step is equal or faster with it (serial pass 3.59 -> 3.50 ms, step 75.1 -> 76.7 k img/s); small grids keep the old rules.
+            if (kn.bf16_w8_min_tiles > 0 && t128 >= kn.bf16_w8_min_tiles) pl.tile = TILE_128x128_W8;
         }
         if (kn.force_bf16 >= 0) pl.tile = kn.force_bf16;
     }
@@ -1005,6 +1011,8 @@ static int finalize_impl(hpe_ctx* c) {
         c->knobs.force_expand = e ? atoi(e) : -1;
         e = getenv("HPE_EXPAND_SMALL_GRID");
         if (e) c->knobs.expand_small_grid = atoi(e);
+        e = getenv("HPE_BF16_W8_MIN_TILES");
+        if (e) c->knobs.bf16_w8_min_tiles = atoi(e);
         e = getenv("HPE_NS_BF16");
         c->knobs.force_ns_bf16 = e ? atoi(e) : -1;
         e = getenv("HPE_BF16_RULES");
