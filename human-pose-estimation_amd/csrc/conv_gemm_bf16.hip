@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 || BM * BN >= 256 * 128) ? (W
     constexpr int BUF = (BM + BN) * RF;
     constexpr int LDS_FLOATS = (NS * BUF > BM * EP) ? NS * BUF : BM * EP;
     constexpr int NDMA = AP + BP;  // LDS-DMA instructions per wave and slab
-    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(AP >= 1 && BP >= 1, "tile too small for the wave count");
     static_assert(NS >= 2 && NS <= 4 && (NS - 2) * NDMA <= 63, "ring depth");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -315,7 +315,6 @@ hipError_t launch_mode_b(GemmArgs& p, int tile, int ns, hipStream_t st) {
         case TILE_64x64: return launch_cfg_b<MODE, 64, 64, 2, 2, 2>(p, st);
         case TILE_64x128: return launch_cfg_b<MODE, 64, 128, 2, 2, 2>(p, st);
         case TILE_128x128_W8: return launch_cfg_b<MODE, 128, 128, 2, 4, 2>(p, st);
-        case TILE_128x128_W16: return launch_cfg_b<MODE, 128, 128, 4, 4, 2>(p, st);
         case TILE_128x64_W8: return launch_cfg_b<MODE, 128, 64, 4, 2, 2>(p, st);
         case TILE_256x128_W8: return launch_ns<MODE, 256, 128, 4, 2>(p, ns, st);
         default: return hipErrorInvalidValue;
@@ -421,7 +420,7 @@ hipError_t hpe_launch_gemm_bf16(GemmArgs p, int mode, int tile, int ns, hipStrea
     if ((p.ldy % 8) != 0 || ((uintptr_t)p.y & 15) != 0) return hipErrorInvalidValue;
     if (p.res && ((p.ldres % 8) != 0 || ((uintptr_t)p.res & 15) != 0)) return hipErrorInvalidValue;
     if (((uintptr_t)p.x & 15) != 0 || ((uintptr_t)p.w & 15) != 0) return hipErrorInvalidValue;
-    const int bn = (tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x128_W8 || tile == TILE_256x128_W8 || tile == TILE_128x128_W16) ? 128 : 64;
+    const int bn = (tile == TILE_128x128 || tile == TILE_64x128 || tile == TILE_128x128_W8 || tile == TILE_256x128_W8) ? 128 : 64;
     if (((p.N + bn - 1) / bn) * bn > p.w_rows) return hipErrorInvalidValue;
     switch (mode) {
         case GEMM_DENSE:

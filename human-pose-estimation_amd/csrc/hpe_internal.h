@@ -8,8 +8,7 @@
 // convolution of a ResNet conv_block and its projection shortcut as ONE launch (weights concatenated along k, BN scales folded in)
 enum GemmMode { GEMM_DENSE = 0, GEMM_STRIDED = 1, GEMM_CONV3 = 2, GEMM_STEM = 3, GEMM_DUAL = 4 };
 enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_64x128 = 3, TILE_128x128_W8 = 4, TILE_128x64_W8 = 5, TILE_256x128_W8 = 6,
-                TILE_P8_256x256 = 7 /* bf16 only: the phase-interleaved 8-wave kernel of conv_gemm_bf16_p8.hip */,
-                TILE_128x128_W16 = 8 /* bf16 only: 16 waves of 32 x 32 (experiment: DMA instructions per wave halved again) */ };
+                TILE_P8_256x256 = 7 /* bf16 only: the phase-interleaved 8-wave kernel of conv_gemm_bf16_p8.hip */ };
 
 // Arguments of the implicit-GEMM kernel (conv_gemm.hip).  All offsets are in floats.
 struct GemmArgs {

@@ -15,7 +15,7 @@ HPE_CHAIN=0 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp
 HPE_CHAIN=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_chain_off.json
 # round 4: the bf16 encoder with its 3x3 layers on the implicit GEMM (halo3 = 0), same box
 HPE_HALO3=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_halo3_off.json
-HPE_HALO3=0 HPE_CHAIN=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_r3_plan.json
+HPE_HALO3=0 HPE_CHAIN=0 HPE_BF16_W8_MIN_TILES=0 python bench.py --steps 30 --warmup 5 --encoder-dtype bf16 $Q 2>/dev/null > $OUT/bench_bf16_r3_plan.json
 HPE_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $OUT/bench_fp32_rccl_world1.json
 HPE_FORCE_DIST=1 python bench.py --steps 30 --warmup 5 $Q --encoder-dtype bf16 2>/dev/null > $OUT/bench_bf16_rccl_world1.json
 HPE_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 $Q --config5 2>/dev/null > $OUT/bench_config5_rccl_world1.json
