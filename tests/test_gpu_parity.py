@@ -1002,7 +1002,8 @@ def _bf16_round(x):
 def engines_bf16_old_and_p8(assets):
     """Two bf16 encoder contexts side by side: the round-2 kernels everywhere (bf16_p8=0) and every eligible layer on the 256 x 256
     phase-interleaved kernel (bf16_p8=31: 3x3, 1x1 / strided and dual-source launches with N % 256 == 0 and K >= 512)."""
-    made = [encoder_engine(assets, 256, encoder_dtype="bf16", bf16_p8=0), encoder_engine(assets, 256, encoder_dtype="bf16", bf16_p8=31)]
+    # halo3=0: the halo-resident 3x3 kernel (round 4, default) would take the 3x3 layers before the tile choice is consulted
+    made = [encoder_engine(assets, 256, encoder_dtype="bf16", bf16_p8=0, halo3=0), encoder_engine(assets, 256, encoder_dtype="bf16", bf16_p8=31, halo3=0)]
     yield made
     for e in made:
         e.close()
