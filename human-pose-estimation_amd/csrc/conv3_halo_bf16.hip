@@ -74,15 +74,17 @@ __device__ __forceinline__ void wait_dma_leaving(int n) {
 
 // HW = map height = width, CIN = input channels, BN = output channels per workgroup, BM = pixels per workgroup (BM / 32 waves),
 // NSW = weight ring depth
-template <int HW, int CIN, int BN, int BM, int NSW>
-__global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_kernel(Halo3Args p) {
+// A1: ONE image buffer also when Cin > 64 (with BN = 64: 72 KB, two workgroups per CU): the next slab's image is requested when the
+// current slab is done -- the bubble is the other workgroup's to fill.
+template <int HW, int CIN, int BN, int BM, int NSW, bool A1 = false>
+__global__ __launch_bounds__(BM * 2, A1 ? 4 : (BM == 256 ? 2 : 1)) void conv3_halo_bf16_kernel(Halo3Args p) {
     constexpr int NW = BM / 32, NTHR = 64 * NW;
     constexpr int CS = CIN / 64;           // 64-channel input slabs
     constexpr int HALO = HW + 1;           // rows in front of / behind the tile that its taps reach
     constexpr int NPIECE = (BM + 2 * HALO + 7) / 8;
     constexpr int API = (NPIECE + NW - 1) / NW;  // activation DMA instructions per wave and image
     constexpr int A_BYTES = API * NW * 1024;
-    constexpr int ABUFS = CS > 1 ? 2 : 1;
+    constexpr int ABUFS = (CS > 1 && !A1) ? 2 : 1;
     constexpr int W_BYTES = BN * 128;      // one weight slab
     constexpr int WI = BN / (8 * NW);      // weight DMA instructions per wave and slab
     // the weight ring sits at the bottom of the LDS: ring buffer + fragment offsets stay below 64 KB, i.e. inside the immediate offset
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
     constexpr int MT = 2, NT = BN / 64;    // wave tile: 64 pixels x BN / 2 channels
     constexpr int SLAB = BM * 128;         // output staging: [BM rows x 64 channels]
     static_assert(CIN % 64 == 0 && BN % 64 == 0 && BN % (8 * NW) == 0 && (BM == 128 || BM == 256), "geometry");
-    static_assert(NSW == 4 && (CS <= 4 || (CS % 4 == 0 && NT == 2)), "ring positions are compile-time constants: 9 = 1 mod 4, period 4 slabs");
-    static_assert(CS == 1 || API <= 6, "the pieces of the next image are requested one per step, taps 0 .. API-1, and are older than W(cs + 1, 0)");
+    static_assert(NSW == 4 && (CS <= 4 || (CS % 4 == 0 && (NT == 2 || A1))), "ring positions are compile-time constants: 9 = 1 mod 4, period 4 slabs");
+    static_assert(CS == 1 || A1 || API <= 6, "the pieces of the next image are requested one per step, taps 0 .. API-1, and are older than W(cs + 1, 0)");
     static_assert((BN / 64) * SLAB <= LDS_BYTES && LDS_BYTES <= 160 * 1024 && NSW * W_BYTES <= 65536, "LDS");
     static_assert((BM * BN / 8) % NTHR == 0, "row stores");
 
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
             for (int g = 0; g < 4; ++g) {
                 if (g == 1 && !(last && tap == 8)) {
                     // younger than W(s + 1): W(s + 2) and the image pieces requested in the two steps before this one
-                    const int na1 = (tap - 1 >= 0 && tap - 1 < API) ? 1 : 0;
-                    const int na2 = (tap - 2 >= 0 && tap - 2 < API) ? 1 : 0;
+                    const int na1 = (!A1 && tap - 1 >= 0 && tap - 1 < API) ? 1 : 0;
+                    const int na2 = (!A1 && tap - 2 >= 0 && tap - 2 < API) ? 1 : 0;
                     const int steady = WI + na1 + na2;
                     const int tail = tap + 2 < 9 ? WI : 0;  // last slab: no image pieces; W(s + 2) exists while tap + 2 < 9
                     if (CS > 1 && !last) wait_dma_leaving(steady);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
                     const int t3 = tap + NSW - 1;
                     if (t3 < 9) issue_w(cs, t3, (R0 + t3) % NSW);
                     else if (!last) issue_w(cs + 1, t3 - 9, (R0 + t3) % NSW);
-                    if (CS > 1 && !last && tap < API) issue_a_piece(cs + 1, tap);
+                    if (CS > 1 && !A1 && !last && tap < API) issue_a_piece(cs + 1, tap);
                 }
                 // read the group two ahead -- (tap, g + 2), or group g - 2 of the next step -- then wait for the current one only
                 constexpr bool LOOPED = CS > 4;  // Cin = 512: the slab groups are a run-time loop and `last` a run-time flag
@@ -274,6 +276,9 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
                     if (g == 2) tap_addr(cs, tap + 1);
                     load_frags(nxt, (R0 + tap + 1) % NSW, g - 2);
                     wait_frags(cur, 2);
+                } else if (A1) {
+                    // one image buffer: nothing of the next slab can be read yet -- the last two groups of the slab drain the pipeline
+                    wait_frags(cur, g == 2 ? 1 : 0);
                 } else if (LOOPED && R0 == NSW - 1) {
                     // The back edge of the slab-group loop (and, on the last pass, the end).  Nothing may cross it in flight: the register
                     // copies the compiler places on a back edge or a branch would copy fragments that have not landed (tools/isa_lint.py
@@ -295,6 +300,22 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
             }
+        }
+        if (A1 && CS > 1 && !last) {
+            // slab boundary with one image buffer: everyone is done reading image cs -> request image cs + 1 -> it has landed everywhere
+            // (the wait also covers the weight slabs in flight, which are L2 hits) -> restart the fragment pipeline.  Nothing is in flight
+            // when the slab function returns (it may be the body of a run-time loop).
+            wait_dma_leaving(2 * WI);  // (at most two weight slabs are in flight here: no wait in effect -- named for tools/isa_lint.py, this barrier publishes no DMA data)
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < API; ++i) issue_a_piece(cs + 1, i);
+            wait_dma_leaving(0);
+            lds_barrier();
+            tap_addr(cs + 1, 0);
+            load_frags(0, (R0 + 9) % NSW, 0);
+            load_frags(1, (R0 + 9) % NSW, 1);
+            wait_frags(0, 1);
+            wait_frags(1, 0);
         }
     };
     // 9 = 1 mod 4: slab cs starts at ring position cs % 4
@@ -354,11 +375,11 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 2 : 1) void conv3_halo_bf16_ker
     }
 }
 
-template <int HW, int CIN, int BN, int BM, int NSW = 4>
+template <int HW, int CIN, int BN, int BM, int NSW = 4, bool A1 = false>
 hipError_t launch_halo3(Halo3Args p, hipStream_t st) {
     p.n_ntiles = p.N / BN;
     const int grid = ((p.M + BM - 1) / BM) * p.n_ntiles;
-    hipLaunchKernelGGL((conv3_halo_bf16_kernel<HW, CIN, BN, BM, NSW>), dim3(grid), dim3(BM * 2), 0, st, p);
+    hipLaunchKernelGGL((conv3_halo_bf16_kernel<HW, CIN, BN, BM, NSW, A1>), dim3(grid), dim3(BM * 2), 0, st, p);
     return hipGetLastError();
 }
 
@@ -374,6 +395,15 @@ hipError_t hpe_launch_halo3_bf16(const Halo3Args& p, int HW, int Cin, hipStream_
     if (!hpe_halo3_bf16_supported(HW, Cin, p.N)) return hipErrorInvalidValue;
     if (p.M <= 0 || p.M % (HW * HW) != 0 || !p.x || !p.w || !p.y || !p.scale || !p.shift || p.ldw < 9 * Cin || (p.ldw % 8) != 0) return hipErrorInvalidValue;
     if ((((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y) & 15) != 0) return hipErrorInvalidValue;
+    // Map sizes (bit mask as halo3, Halo3Args::two) that run the two-workgroups-per-CU form: 64 output channels per workgroup and ONE
+    // image buffer (72 KB).  The caller's default is the 28 x 28 maps only -- with two 64-channel slabs a tile is 18 steps, a quarter of
+    // its time is prologue (first image) and epilogue (row stores), and a second resident workgroup fills that: 0.078 -> 0.063 ms per
+    // layer.  On the 14 x 14 maps (36 steps) it measures the same, on the 7 x 7 maps (72 steps) 3 % slower: there the reload of the
+    // single image buffer at every slab boundary costs what the overlap gains.
+    const int two = p.two;
+    if (HW == 28 && (two & 4)) return launch_halo3<28, 128, 64, 256, 4, true>(p, st);
+    if (HW == 14 && (two & 2)) return launch_halo3<14, 256, 64, 256, 4, true>(p, st);
+    if (HW == 7 && (two & 1)) return launch_halo3<7, 512, 64, 256, 4, true>(p, st);
     switch (HW) {
         case 56: return launch_halo3<56, 64, 64, 256>(p, st);
         case 28: return launch_halo3<28, 128, 128, 256>(p, st);

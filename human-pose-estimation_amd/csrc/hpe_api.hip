@@ -201,6 +201,7 @@ struct hpe_ctx {
     unsigned pipe_idx = 0;
     float* feat_alt = nullptr;
     int wino4_ksplit = 1;  // plan option wino4_ksplit / HPE_WINO4_KSPLIT
+    int halo3_two = 4;     // HPE_HALO3_TWO: map sizes of halo3 on the two-workgroups-per-CU form of that kernel (default: 28x28)
     int halo3 = 0;         // bf16 only: map sizes (1 = 7x7, 2 = 14x14, 4 = 28x28, 8 = 56x56) whose 3x3 layers run on conv3_halo_bf16.hip; plan option halo3 / HPE_HALO3
     int chain_fuse = 0;    // bf16 only: stages (bit 0: stage 2, bit 1: stage 3) whose identity blocks run branch2c + the next block's branch2a as
                            // one launch (conv_chain_bf16.hip); plan option chain_fuse / HPE_CHAIN
@@ -433,6 +434,7 @@ hipError_t run_conv(hpe_ctx* c, int idx, const float* x, int B, const float* res
         h.N = s.cout;
         h.ldw = L.k_pad;
         h.relu = relu;
+        h.two = c->halo3_two;
         return hpe_launch_halo3_bf16(h, s.hin, s.cin, st);
     }
     if (c->bf16) {
@@ -991,6 +993,7 @@ static int finalize_impl(hpe_ctx* c) {
         c->wino4_ksplit = opt(c->cfg.wino4_ksplit, "HPE_WINO4_KSPLIT", 1);
         c->chain_fuse = c->bf16 ? (opt(c->cfg.chain_fuse, "HPE_CHAIN", 7) & 23) : (opt(c->cfg.chain_fuse, "HPE_CHAIN", 8) & 8);
         c->halo3 = c->bf16 ? (opt(c->cfg.halo3, "HPE_HALO3", 15) & 15) : 0;
+        c->halo3_two = opt(-1, "HPE_HALO3_TWO", 4) & 7;
         c->wino4_fused = c->wino_min_c > 0 ? (opt(c->cfg.wino4_fused, "HPE_WINO4_FUSED", 0) & 12) : 0;
         const char* e;
         e = getenv("HPE_CONCURRENT_TILES");

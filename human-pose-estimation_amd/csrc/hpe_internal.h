@@ -103,6 +103,7 @@ struct Halo3Args {
     __bf16* y;           // [M, N]
     int M, N, ldw, relu;
     int n_ntiles;        // filled by the launcher
+    int two;             // map sizes (bit mask: 1 = 7x7, 2 = 14x14, 4 = 28x28) on the two-workgroups-per-CU form (64 channels per workgroup, one image buffer)
 };
 bool hpe_halo3_bf16_supported(int HW, int Cin, int N);
 hipError_t hpe_launch_halo3_bf16(const Halo3Args& p, int HW, int Cin, hipStream_t st);

@@ -1131,6 +1131,40 @@ def test_bf16_halo3_full_size_layer_equals_round2_kernel(engines_bf16_halo_off_o
         assert np.array_equal(cpu(on.debug_conv(idx, x, relu=True)), y_new), rep
 
 
+@pytest.mark.parametrize("two", ["0", "7"])
+@pytest.mark.parametrize("name", ["res3c_branch2b", "res4d_branch2b", "res5b_branch2b"])
+def test_bf16_halo3_both_forms_match_oracle(engines_bf16_halo_off_on, assets, name, two):
+    """The kernel has two forms per map size: 128 output channels per workgroup with two image buffers (one workgroup per CU) and 64
+    channels with one buffer that is reloaded at every 64-channel input slab (two per CU).  The default uses the second on the 28 x 28
+    maps only (HPE_HALO3_TWO=4); here every map size runs on each form (0 / 7), at B = 37 (partial last tile) and at the metric batch,
+    against the fp64 convolution of the rounded operands, the implicit-GEMM kernel, and itself (bitwise repeats)."""
+    off, _ = engines_bf16_halo_off_on
+    eng = _engine_with_env(assets, {"HPE_HALO3_TWO": two}, 256, encoder_dtype="bf16", halo3=15)
+    try:
+        idx = resnet_spec.CONV_INDEX[name]
+        s = resnet_spec.CONV_SPECS[idx]
+        g = np.random.Generator(np.random.Philox(2900 + idx))
+        x = g.normal(0, 1, (37, s.hin, s.hin, s.cin)).astype(np.float32)
+        x[g.random(x.shape) < 0.3] = 0.0
+        x[0, 0, 0, :] = 20.0
+        x[:, :, -1, 1] -= 3.0
+        y = cpu(eng.debug_conv(idx, gpu(x), relu=True))
+        p = assets["enc"]
+        sc, sh = _bn_fold(p, s)
+        ref = np.maximum(O.conv2d_nhwc(_bf16_round(x), _bf16_round(p[s.name + "/kernel"]), p[s.name + "/bias"], 1, 1, dtype=np.float64) * sc + sh, 0)
+        assert rel(y, ref) < 2.0 ** -8, rel(y, ref)
+        big = gpu(np.maximum(g.normal(0, 1, (256, s.hin, s.hin, s.cin)), 0).astype(np.float32))
+        y_new = cpu(eng.debug_conv(idx, big, relu=True))
+        y_old = cpu(off.debug_conv(idx, big, relu=True))
+        # different fp32 summation order: single one-ulp flips of the bf16 result (2^-8 ... 2^-7 of the value), nothing systematic
+        assert rel(y_new, y_old) <= 2.0 ** -7, rel(y_new, y_old)
+        assert float(np.linalg.norm(y_new - y_old) / np.linalg.norm(y_old)) < 1e-3
+        for rep in range(10):
+            assert np.array_equal(cpu(eng.debug_conv(idx, big, relu=True)), y_new), rep
+    finally:
+        eng.close()
+
+
 def test_bf16_halo3_encoder_matches_round2_encoder(engines_bf16_halo_off_on, assets):
     """Whole bf16 encoder with all sixteen 3x3 layers on the halo-resident kernel: features within the bf16 tolerance of the implicit-GEMM
     plan and of the rounding-point-emulating oracle; one chunk, two concurrent chunks, repeats bitwise equal."""
