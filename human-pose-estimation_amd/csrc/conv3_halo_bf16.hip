@@ -1,19 +1,28 @@
 // conv3_halo_bf16.hip -- 3x3 / stride 1 / SAME convolution in bf16 with the activation tile AND its halo resident in LDS (round 4).
 //
 // Why: the implicit-GEMM kernel (conv_gemm_bf16.hip) treats the 9 taps as 9 k-slabs and DMAs the activation rows of a tile into LDS once
-// PER TAP: a 128 x 128 tile moves 32 KB into LDS per 2.1 MFLOP (64 FLOP/B).  The L2 -> LDS fill of the whole chip saturates at
-// ~10-11 TB/s (~42 GB/s per CU; every stage 3-5 layer of the bf16 encoder measures 9.4-10.7 TB/s of fill), which caps that kernel at
-// 0.6-0.7 PFLOP/s -- 28 % of the bf16 matrix rate -- whatever the HBM traffic is.  Here a workgroup owns BM consecutive pixels of the
+// PER TAP: a 128 x 128 tile moves 32 KB into LDS per 2.1 MFLOP (64 FLOP/B).  The LDS-DMA staging path of these kernels delivers
+// ~10-11 TB/s chip-wide (~42 GB/s per CU; every stage 3-5 layer of the bf16 encoder measures 8.2-10.7 TB/s of fill -- paced by the issue
+// of the DMA instructions), which caps that kernel at 0.6-0.7 PFLOP/s -- 28 % of the bf16 matrix rate -- whatever
+// the HBM traffic is.  Here a workgroup owns BM consecutive pixels of the
 // flattened [B*H*W] axis and stages, per 64-channel input slab, the BM + 2(W+1) activation rows ONCE; the 9 taps read it at 9 row shifts.
 // Out-of-image taps read a zero row instead (one v_cndmask on the address, not on the data).  What still streams per tap is the
 // [BN x 64] weight slab: fill per step (BM = 256, BN = 128) = 16 KB weights + 4.4 KB of the next activation image for 4.2 MFLOP = 205 FLOP/B.
+// Measured (B = 256, ms per layer, implicit GEMM -> this kernel): 56x56 0.103 -> 0.070, 28x28 0.090 -> 0.063, 14x14 0.084 -> 0.0615,
+// 7x7 0.085 -> 0.0605 (profiles/r04/layers_bf16_halo3_ab.txt).
 //
-// Structure: steps s = (input slab cs, tap t), 9 CS of them; one barrier per step.
-//   * weights: ring of 3 slabs ([BN rows x 128 B], XOR-swizzled like every slab here), W(s + 2) requested after the barrier of step s;
-//     9 taps per input slab and a ring of 3 make the ring position t % 3, a compile-time constant in the unrolled tap loop
-//   * activations: two images (one when Cin = 64); the pieces of image cs + 1 are requested one per step during taps 0 .. API-1 of slab cs
-//   * every wave issues the same number of DMA instructions per step, so "slab s has landed" is a counted vmcnt wait (loads complete in
-//     order) in front of the barrier; no stores inside the loop
+// Structure: steps s = (input slab cs, tap t), 9 CS of them; one barrier per step; four 16-deep fragment groups per step.
+//   * weights: ring of 4 slabs ([BN rows x 128 B], XOR-swizzled like every slab here) at the bottom of the LDS, W(s + 3) requested in
+//     the middle of step s.  9 = 1 mod 4: slab cs starts at ring position cs mod 4; the slab loop is unrolled by 4, so every ring
+//     position is a compile-time constant and goes into the immediate offset of the fragment reads
+//   * activations: two image buffers (one when Cin = 64, and in the A1 form); the pieces of image cs + 1 are requested one per step
+//     during taps 0 .. API-1 of slab cs (A1: all at the slab boundary -- two workgroups per CU cover the bubble)
+//   * the step's barrier sits between fragment groups 0 and 1 and is about the NEXT step ("W(s + 1) has landed everywhere, everyone is
+//     past step s - 1"): the first groups of step s + 1 are read while step s still multiplies
+//   * every wave issues the same number of DMA instructions per step, so "slab s + 1 has landed" is a counted vmcnt wait (loads complete
+//     in order) in front of the barrier; no stores inside the loop
+//   * fragment reads: inline asm, three register sets, the two groups after the current one in flight behind counted lgkmcnt waits
+//     (below: why, and what tools/isa_lint.py checks about it)
 //   * accumulators transposed (weight fragment = MFMA operand A): a lane owns one pixel x 4 consecutive channels, so the epilogue writes
 //     8-B pieces into an LDS image of the output tile, which leaves as 16-B row stores
 // Oracle: tests/test_gpu_parity.py::test_bf16_halo3_* against the fp64 convolution of the bf16-rounded operands and the round-2 kernel.

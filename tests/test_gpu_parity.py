@@ -1165,6 +1165,23 @@ def test_bf16_halo3_both_forms_match_oracle(engines_bf16_halo_off_on, assets, na
         eng.close()
 
 
+def test_bf16_halo3_forms_are_bitwise_equal(assets):
+    """Both forms add the same products in the same order (input slab, tap, 16-deep group): which one runs is a scheduling choice, the
+    result does not depend on it."""
+    e0 = _engine_with_env(assets, {"HPE_HALO3_TWO": "0"}, 64, encoder_dtype="bf16", halo3=15)
+    e7 = _engine_with_env(assets, {"HPE_HALO3_TWO": "7"}, 64, encoder_dtype="bf16", halo3=15)
+    try:
+        for name in ("res3b_branch2b", "res4b_branch2b", "res5c_branch2b"):
+            idx = resnet_spec.CONV_INDEX[name]
+            s = resnet_spec.CONV_SPECS[idx]
+            g = np.random.Generator(np.random.Philox(3100 + idx))
+            x = gpu(g.normal(0, 1, (41, s.hin, s.hin, s.cin)).astype(np.float32))
+            assert np.array_equal(cpu(e0.debug_conv(idx, x, relu=True)), cpu(e7.debug_conv(idx, x, relu=True))), name
+    finally:
+        e0.close()
+        e7.close()
+
+
 def test_bf16_halo3_encoder_matches_round2_encoder(engines_bf16_halo_off_on, assets):
     """Whole bf16 encoder with all sixteen 3x3 layers on the halo-resident kernel: features within the bf16 tolerance of the implicit-GEMM
     plan and of the rounding-point-emulating oracle; one chunk, two concurrent chunks, repeats bitwise equal."""
